@@ -1,0 +1,81 @@
+"""Per-pair camera algebra of grid2sample_locs, kept on the host in float32.
+
+The reference computes, per (reference, source) pair, a 4x3 pseudo-inverse by
+SVD, a 3x3 inverse and the epipole in float32 (modeling/layers/epipolar.py:336,
+344-348; vision/multiview.py:16-21).  With cond(P) ~ 1e6 those roundings move
+sample locations by up to 4e-3, so parity with the
+reference's CPU path requires *these exact* float32 values; every per-pixel step
+after them runs on the GPU.  This module produces them batched -- bit-identical
+to the reference's per-matrix loop at ~0.4 ms for 128 pairs instead of ~4 ms --
+and packs them in the `cam` layout of include/epipolar_amd.h (ET_CAM_STRIDE).
+"""
+from __future__ import annotations
+
+import torch
+
+ET_CAM_STRIDE = 27
+
+
+def batched_pinverse(P: torch.Tensor) -> torch.Tensor:
+    """`torch.stack([p.pinverse() for p in P])` (epipolar.py:336), batched.
+
+    torch.pinverse(A) is (Vh^T * 1/S) @ U^T from the LAPACK SVD.  The batched
+    SVD is bit-identical to the per-matrix one; the tiny product is not when
+    done by bmm (no FMA) instead of mm (BLAS, ascending-k FMA chain), so the
+    FMA chain is spelled out here through float64 (exact products).
+    """
+    U, S, Vh = torch.linalg.svd(P, full_matrices=False)
+    cutoff = 1e-15 * S.amax(-1, keepdim=True)          # pinverse's default rcond
+    s_inv = torch.where(S > cutoff, 1.0 / S, torch.zeros_like(S))
+    A = (Vh.transpose(-1, -2) * s_inv.unsqueeze(-2)).double()      # (N,4,3)
+    B = U.transpose(-1, -2).double()                               # (N,3,3)
+    acc = (A[..., :, 0:1] * B[..., 0:1, :]).float()
+    acc = (A[..., :, 1:2] * B[..., 1:2, :] + acc.double()).float()
+    acc = (A[..., :, 2:3] * B[..., 2:3, :] + acc.double()).float()
+    return acc
+
+
+def pair_algebra(P_ref: torch.Tensor, P_src: torch.Tensor) -> torch.Tensor:
+    """(N,3,4),(N,3,4) -> (N,27) float32 CPU tensor [P1inv | P2 | e2].
+
+    Inputs may live on any device; they are brought to the CPU (a GPU-resident
+    P costs one small synchronising copy -- pass CPU tensors, as the data
+    loader produces them, to keep the launch path asynchronous)."""
+    P1 = P_ref.detach().to("cpu", torch.float32)
+    P2 = P_src.detach().to("cpu", torch.float32)
+    if P1.dim() != 3 or P1.shape[1:] != (3, 4) or P2.shape != P1.shape:
+        raise ValueError("expected two (N,3,4) projection-matrix batches, got %s and %s"
+                         % (tuple(P_ref.shape), tuple(P_src.shape)))
+    n = P1.shape[0]
+    p1inv = batched_pinverse(P1)
+    inv_a = torch.inverse(P1[..., :3])                               # multiview.py:17
+    centre = -torch.matmul(inv_a, P1[..., 3, None])                  # multiview.py:18
+    hom = torch.ones([n, 4, 1], dtype=torch.float32)                 # multiview.py:19-20
+    hom[..., :3, :] = centre
+    e2 = torch.matmul(P2, hom).view(n, 3, 1)                         # epipolar.py:346
+    e2 = e2 / e2[:, [2], :]                                          # epipolar.py:348
+    return torch.cat([p1inv.reshape(n, 12), P2.reshape(n, 12), e2.reshape(n, 3)], 1).contiguous()
+
+
+class PairAlgebraCache:
+    """Small value-keyed cache (camera rigs repeat across frames and steps).
+    Keyed on the bytes of the matrices, never on tensor identity (SURVEY.md 8b
+    "Ownership")."""
+
+    def __init__(self, max_entries: int = 8):
+        self.max_entries = max_entries
+        self._store = {}
+
+    def get(self, P_ref: torch.Tensor, P_src: torch.Tensor, device) -> torch.Tensor:
+        a = P_ref.detach().to("cpu", torch.float32).contiguous()
+        b = P_src.detach().to("cpu", torch.float32).contiguous()
+        key = (a.numpy().tobytes(), b.numpy().tobytes(), str(device))
+        hit = self._store.get(key)
+        if hit is None:
+            cam = pair_algebra(a, b)
+            if torch.device(device).type == "cuda":
+                cam = cam.pin_memory().to(device, non_blocking=True)
+            if len(self._store) >= self.max_entries:
+                self._store.pop(next(iter(self._store)))
+            self._store[key] = hit = cam
+        return hit

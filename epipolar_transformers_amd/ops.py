@@ -1,0 +1,197 @@
+"""Torch-facing wrappers of the C ABI (torch is plumbing: device memory, the
+current HIP stream and autograd bookkeeping; all arithmetic of the path is in
+the HIP library).  Feature tensors are logical NCHW like the reference's; their
+memory is NHWC (torch.channels_last), converted once with our own kernel when a
+caller hands NCHW-contiguous memory."""
+from __future__ import annotations
+
+import ctypes
+from dataclasses import dataclass
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import EtLayerDesc
+
+
+@dataclass
+class LayerSpec:
+    """The static part of an EtLayerDesc + the three small constant arrays the
+    reference builds in Epipolar.__init__ (epipolar.py:22-54)."""
+
+    H: int
+    W: int
+    K: int
+    downsample: float = 4.0
+    image_resize: float = 1.0
+    predict_resize: float = 1.0
+    correct_normalize: bool = True
+    align_corners: bool = False
+    softmax_scale: float = 0.125
+    softmax_enabled: bool = True
+    eps: float = 0.001
+    src_grad_mask: int = 3
+    variant: int = 0
+
+    def __post_init__(self):
+        ds = self.downsample
+        # pix2coord (multiview.py:154-157) * resize factors, same float32 op order as epipolar.py:35-38
+        y = torch.arange(0, self.H, dtype=torch.float)
+        x = torch.arange(0, self.W, dtype=torch.float)
+        y = (y * ds + ds / 2.0 - 0.5) * self.image_resize * self.predict_resize
+        x = (x * ds + ds / 2.0 - 0.5) * self.image_resize * self.predict_resize
+        self.xs, self.ys = x.contiguous(), y.contiguous()
+        # torch.range(0, 1, 1/(K-1)) (epipolar.py:54): start + i*step in double, rounded to float32
+        step = 1.0 / (self.K - 1)
+        self.steps = torch.from_numpy((np.arange(self.K, dtype=np.float64) * step).astype(np.float32))
+        self._dev = {}
+
+    def constants(self, device):
+        """xs, ys, steps resident on `device` (uploaded once per device)."""
+        key = str(device)
+        if key not in self._dev:
+            self._dev[key] = tuple(t.to(device) for t in (self.xs, self.ys, self.steps))
+        return self._dev[key]
+
+    def desc(self, N: int, C: int) -> EtLayerDesc:
+        return EtLayerDesc(
+            N=N, C=C, H=self.H, W=self.W, K=self.K,
+            xmin=float(self.xs[0]), ymin=float(self.ys[0]), xmax=float(self.xs[-1]), ymax=float(self.ys[-1]),
+            eps=self.eps, downsample=float(self.downsample), image_resize=float(self.image_resize),
+            predict_resize=float(self.predict_resize), correct_normalize=int(self.correct_normalize),
+            align_corners=int(self.align_corners), softmax_scale=float(self.softmax_scale),
+            softmax_enabled=int(self.softmax_enabled), src_grad_mask=int(self.src_grad_mask),
+            variant=int(self.variant))
+
+
+def _require_gpu(t: torch.Tensor, name: str):
+    if not t.is_cuda:
+        raise _lib.EpipolarAmdError(
+            "%s is on %s: the epipolar hot path runs on the GPU only (no CPU fallback)" % (name, t.device))
+    if t.dtype != torch.float32:
+        raise TypeError("%s must be float32, got %s" % (name, t.dtype))
+
+
+def _stream(t: torch.Tensor):
+    return ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+
+
+def to_nhwc(x: torch.Tensor) -> torch.Tensor:
+    """Logical (N,C,H,W) -> contiguous (N,H,W,C) memory.  Zero-copy when x is
+    already channels_last; otherwise one pass of et_nchw_to_nhwc."""
+    _require_gpu(x, "feature map")
+    n, c, h, w = x.shape
+    perm = x.permute(0, 2, 3, 1)
+    if perm.is_contiguous():
+        return perm
+    src = x.contiguous()
+    dst = torch.empty((n, h, w, c), dtype=x.dtype, device=x.device)
+    with torch.cuda.device(x.device):
+        _lib.check(_lib.load().et_nchw_to_nhwc(n, c, h, w, _ptr(src), _ptr(dst), _stream(x)), "et_nchw_to_nhwc")
+    return dst
+
+
+def to_nchw_contiguous(x_nhwc: torch.Tensor) -> torch.Tensor:
+    """(N,H,W,C) memory -> NCHW-contiguous tensor via et_nhwc_to_nchw."""
+    _require_gpu(x_nhwc, "feature map")
+    n, h, w, c = x_nhwc.shape
+    dst = torch.empty((n, c, h, w), dtype=x_nhwc.dtype, device=x_nhwc.device)
+    with torch.cuda.device(x_nhwc.device):
+        _lib.check(_lib.load().et_nhwc_to_nchw(n, c, h, w, _ptr(x_nhwc.contiguous()), _ptr(dst), _stream(x_nhwc)),
+                   "et_nhwc_to_nchw")
+    return dst
+
+
+def sample_locs(spec: LayerSpec, cam: torch.Tensor) -> torch.Tensor:
+    """grid2sample_locs (epipolar.py:323-418): (K,N,H,W,2)."""
+    _require_gpu(cam, "cam")
+    n = cam.shape[0]
+    xs, ys, steps = spec.constants(cam.device)
+    out = torch.empty((spec.K, n, spec.H, spec.W, 2), dtype=torch.float32, device=cam.device)
+    d = spec.desc(n, 4)
+    with torch.cuda.device(cam.device):
+        _lib.check(_lib.load().et_sample_locs(ctypes.byref(d), _ptr(xs), _ptr(ys), _ptr(steps), _ptr(cam), _ptr(out),
+                                              _stream(cam)), "et_sample_locs")
+    return out
+
+
+def forward_nhwc(spec: LayerSpec, ref: torch.Tensor, src: torch.Tensor, cam: torch.Tensor,
+                 want_attn=True, want_corr=True):
+    """ref/src: (N,H,W,C) contiguous.  Returns out (N,H,W,C), attn (N,K,H,W)|None, corr_pos (N,H,W,2)|None."""
+    for t, nm in ((ref, "feat_ref"), (src, "feat_src"), (cam, "cam")):
+        _require_gpu(t, nm)
+    n, h, w, c = ref.shape
+    if (h, w) != (spec.H, spec.W) or src.shape != ref.shape:
+        raise ValueError("feature maps %s / %s do not match the layer's %dx%d" %
+                         (tuple(ref.shape), tuple(src.shape), spec.H, spec.W))
+    if cam.shape != (n, _lib.ET_CAM_STRIDE) or not cam.is_contiguous():
+        raise ValueError("cam must be a contiguous (N,%d) tensor" % _lib.ET_CAM_STRIDE)
+    assert ref.is_contiguous() and src.is_contiguous()
+    xs, ys, steps = spec.constants(ref.device)
+    out = torch.empty_like(ref)
+    attn = torch.empty((n, spec.K, h, w), dtype=torch.float32, device=ref.device) if want_attn else None
+    corr = torch.empty((n, h, w, 2), dtype=torch.float32, device=ref.device) if want_corr else None
+    d = spec.desc(n, c)
+    with torch.cuda.device(ref.device):
+        _lib.check(_lib.load().et_epipolar_forward(ctypes.byref(d), _ptr(xs), _ptr(ys), _ptr(steps), _ptr(cam),
+                                                   _ptr(ref), _ptr(src), _ptr(out), _ptr(attn), _ptr(corr),
+                                                   _stream(ref)), "et_epipolar_forward")
+    return out, attn, corr
+
+
+def backward_nhwc(spec: LayerSpec, ref, src, cam, grad_out):
+    n, h, w, c = ref.shape
+    xs, ys, steps = spec.constants(ref.device)
+    grad_out = grad_out.contiguous()
+    g_ref = torch.empty_like(ref)
+    g_src = torch.empty_like(src)
+    d = spec.desc(n, c)
+    with torch.cuda.device(ref.device):
+        _lib.check(_lib.load().et_epipolar_backward(ctypes.byref(d), _ptr(xs), _ptr(ys), _ptr(steps), _ptr(cam),
+                                                    _ptr(ref), _ptr(src), _ptr(grad_out), _ptr(g_ref), _ptr(g_src),
+                                                    _stream(ref)), "et_epipolar_backward")
+    return g_ref, g_src
+
+
+def residual_epilogue(feat, out, y=None, scale=None, shift=None, want_finalout=True, want_x=True):
+    """All (N,H,W,C) contiguous.  finalout = out + y*scale + shift ; x = feat + finalout."""
+    n, h, w, c = out.shape
+    fin = torch.empty_like(out) if want_finalout else None
+    x = torch.empty_like(out) if want_x else None
+    with torch.cuda.device(out.device):
+        _lib.check(_lib.load().et_residual_epilogue(n * h * w, c, _ptr(feat), _ptr(out), _ptr(y), _ptr(scale),
+                                                    _ptr(shift), _ptr(fin), _ptr(x), _stream(out)),
+                   "et_residual_epilogue")
+    return fin, x
+
+
+class EpipolarAttend(torch.autograd.Function):
+    """out = sum_k softmax_k(scale * mask(f_ref . S_k)) S_k with S_k the K bilinear
+    samples of f_src on the pixel's epipolar segment (epipolar.py:188-247).
+    Inputs/outputs are logical NCHW; attn and corr_pos are returned without
+    gradient (the reference never back-propagates through them in the
+    configurations of BASELINE.json)."""
+
+    @staticmethod
+    def forward(ctx, feat_ref, feat_src, cam, spec: LayerSpec):
+        ref = to_nhwc(feat_ref)
+        src = to_nhwc(feat_src)
+        out, attn, corr = forward_nhwc(spec, ref, src, cam)
+        ctx.spec = spec
+        ctx.save_for_backward(ref, src, cam)
+        ctx.mark_non_differentiable(attn, corr)
+        return out.permute(0, 3, 1, 2), attn, corr
+
+    @staticmethod
+    def backward(ctx, grad_out, _ga, _gc):
+        ref, src, cam = ctx.saved_tensors
+        g = to_nhwc(grad_out)
+        g_ref, g_src = backward_nhwc(ctx.spec, ref, src, cam, g)
+        need_ref, need_src = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        return (g_ref.permute(0, 3, 1, 2) if need_ref else None,
+                g_src.permute(0, 3, 1, 2) if need_src else None, None, None)

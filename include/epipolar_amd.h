@@ -1,0 +1,130 @@
+/*
+ * epipolar_amd.h -- C ABI of the MI355X-native Epipolar Transformer hot path.
+ *
+ * Drop-in boundary: these entry points are what a
+ * binding of the reference's `Epipolar` operator
+ * (modeling/layers/epipolar.py:11-269, called from
+ * modeling/backbones/resnet.py:377-388) calls instead of the per-sample Python
+ * loop.  Plain pointers and sizes only; no torch types.  Every pointer is a
+ * DEVICE pointer unless its comment says "host".  The library allocates
+ * nothing, never synchronises the device and enqueues all work on `stream`
+ * (a hipStream_t passed as void*; NULL = the default stream), so it is
+ * re-entrant under nn.DataParallel-style threading (SURVEY.md 8b "Threading").
+ *
+ * Return value: 0 on success, non-zero on error; et_last_error() then returns
+ * a thread-local description.  No error is ever turned into NaNs silently.
+ *
+ * Feature maps are channels-last: (N, H, W, C) float32, C contiguous, C % 4 == 0.
+ * (The reference hands NCHW tensors; et_nchw_to_nhwc / et_nhwc_to_nchw convert,
+ * and a torch tensor in torch.channels_last memory format already IS this
+ * layout.)
+ */
+#ifndef EPIPOLAR_AMD_H_
+#define EPIPOLAR_AMD_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ET_ABI_VERSION 1
+
+/* Static description of one layer call: the cfg keys the reference reads in
+ * Epipolar.__init__ (epipolar.py:12-54) and at call time (epipolar.py:303-311,
+ * 409-414; vision/multiview.py:25-57,154-163). */
+typedef struct EtLayerDesc {
+    int32_t N;                 /* (reference view, source view) pairs in the batch          */
+    int32_t C;                 /* cfg.KEYPOINT.NFEATS (channels), multiple of 4             */
+    int32_t H, W;              /* cfg.KEYPOINT.HEATMAP_SIZE                                 */
+    int32_t K;                 /* cfg.EPIPOLAR.SAMPLESIZE, 2 <= K <= 256                    */
+    float xmin, ymin;          /* epipolar.py:46-47 (first pixel centre, image coords)      */
+    float xmax, ymax;          /* epipolar.py:48-49 (last pixel centre)                     */
+    float eps;                 /* epipolar.py:20  (0.001)                                   */
+    float downsample;          /* cfg.BACKBONE.DOWNSAMPLE            (multiview.py:159-163) */
+    float image_resize;        /* cfg.DATASETS.IMAGE_RESIZE          (epipolar.py:411)      */
+    float predict_resize;      /* cfg.DATASETS.PREDICT_RESIZE        (epipolar.py:411)      */
+    int32_t correct_normalize; /* cfg.EPIPOLAR.USE_CORRECT_NORMALIZE (multiview.py:29,45)   */
+    int32_t align_corners;     /* F.grid_sample semantics (epipolar.py:199): 0 = torch>=1.3 default */
+    float softmax_scale;       /* cfg.EPIPOLAR.SOFTMAXSCALE          (epipolar.py:306)      */
+    int32_t softmax_enabled;   /* cfg.EPIPOLAR.SOFTMAX_ENABLED       (epipolar.py:303-311)  */
+    int32_t src_grad_mask;     /* backward only, cfg.EPIPOLAR.OTHER_GRAD (epipolar.py:141-153):
+                                  bit0 = gradient reaches feat_src through the similarity ('other1'),
+                                  bit1 = through the sampled values ('other2'); reference default 3 */
+    int32_t variant;           /* kernel variant bits, 0 = library default (tuning/ablation) */
+} EtLayerDesc;
+
+/* Floats per pair in the `cam` array consumed below:
+ *   [0..11]  P1inv  4x3 row-major : pinverse(P_ref)            epipolar.py:336
+ *   [12..23] P2     3x4 row-major : P_src                      epipolar.py:340
+ *   [24..26] e2     epipole P2 @ centre(P_ref), divided by z   epipolar.py:344-348
+ * This O(N) algebra stays on the host in float32 torch. */
+#define ET_CAM_STRIDE 27
+
+/* Variant bits (EtLayerDesc.variant) */
+#define ET_VARIANT_SAFE_REDUCE 1  /* cross-lane sums via ds_bpermute only (no permlane swaps / DPP) */
+#define ET_VARIANT_NO_TAP_CACHE 2 /* reload all four taps for every sample                          */
+
+int et_abi_version(void);
+const char *et_last_error(void);
+
+/* grid2sample_locs (epipolar.py:323-418).
+ *   xs[W], ys[H] : pixel-centre grid in image coordinates       epipolar.py:35-38
+ *   steps[K]     : torch.range(0, 1, 1/(K-1))                   epipolar.py:54
+ *   cam[N*27]    : see ET_CAM_STRIDE
+ *   sample_locs  : (K, N, H, W, 2) normalised coordinates, as the reference returns them */
+int et_sample_locs(const EtLayerDesc *desc, const float *xs, const float *ys, const float *steps,
+                   const float *cam, float *sample_locs, void *stream);
+
+/* Fused hot loop of Epipolar.forward in the headline mode (MERGE late,
+ * ATTENTION avg, SIMILARITY dot): epipolar.py:178-247 + epipolar_similarity
+ * (272-321) + de_normalize (multiview.py:39-57), never materialising
+ * sample_locs or the K x C x H x W sampled tensor.
+ *   feat_ref, feat_src : (N,H,W,C)
+ *   out                : (N,H,W,C)  sum_k attn_k * sampled_k           (epipolar.py:243)
+ *   attn      nullable : (N,K,H,W)  the reference's `depth` return     (epipolar.py:263)
+ *   corr_pos  nullable : (N,H,W,2)  de-normalised arg-max sample       (epipolar.py:237-242) */
+int et_epipolar_forward(const EtLayerDesc *desc, const float *xs, const float *ys, const float *steps,
+                        const float *cam, const float *feat_ref, const float *feat_src, float *out,
+                        float *attn, float *corr_pos, void *stream);
+
+/* Backward of et_epipolar_forward w.r.t. both feature maps (sample locations
+ * carry no gradient, epipolar.py:178-183).  Everything is recomputed from the
+ * inputs; nothing saved by the forward is needed.
+ *   grad_out  : (N,H,W,C)
+ *   grad_ref  : (N,H,W,C) written
+ *   grad_src  : (N,H,W,C) zero-filled by this call on `stream`, then
+ *               accumulated with float atomics (bilinear-transpose scatter) */
+int et_epipolar_backward(const EtLayerDesc *desc, const float *xs, const float *ys, const float *steps,
+                         const float *cam, const float *feat_ref, const float *feat_src,
+                         const float *grad_out, float *grad_ref, float *grad_src, void *stream);
+
+/* Residual fusion epilogue: x = feat + out + (y * scale[c] + shift[c])
+ *   (epipolar.py:250-253 with ZRESIDUAL, then resnet.py:388 `ret + feat`),
+ * y = z(out) is the 1x1-conv (GEMM) result, scale/shift = batch-norm affine
+ * folded with its (running or batch) statistics.  y/scale/shift may be NULL
+ * for the un-parameterised layer (x = feat + out).  finalout nullable:
+ * receives out + y*scale + shift (what Epipolar.forward returns).  All (N,H,W,C). */
+int et_residual_epilogue(int64_t num_pixels, int32_t C, const float *feat, const float *out,
+                         const float *y, const float *scale, const float *shift, float *finalout,
+                         float *x, void *stream);
+
+/* Layout converters between the reference's NCHW and the kernels' NHWC. */
+int et_nchw_to_nhwc(int32_t N, int32_t C, int32_t H, int32_t W, const float *src, float *dst, void *stream);
+int et_nhwc_to_nchw(int32_t N, int32_t C, int32_t H, int32_t W, const float *src, float *dst, void *stream);
+
+/* Test hook (HOST pointers, runs on the CPU, no GPU needed): evaluates the
+ * per-sample set-up code that is shared with the device kernels for ONE pair
+ * (cam points at its 27 floats), pixel (h, w): taps[k*4 + r] = linear index
+ * y*W+x of the source pixel routed to tap register r (-1: outside the image),
+ * weights[k*4 + r] = its bilinear weight, locs[k*2 .. k*2+1] = normalised
+ * sample location.  It computes no features and is not a CPU fallback of the
+ * path. */
+int et_debug_host_sample_setup(const EtLayerDesc *desc, const float *xs, const float *ys,
+                               const float *steps, const float *cam, int32_t h, int32_t w,
+                               int32_t *taps, float *weights, float *locs);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EPIPOLAR_AMD_H_ */

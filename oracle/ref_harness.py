@@ -18,8 +18,6 @@ What is shimmed:
 """
 from __future__ import annotations
 
-import ast
-import copy
 import os
 import sys
 import types
@@ -31,96 +29,14 @@ def reference_available() -> bool:
     return os.path.isdir(os.path.join(REFERENCE_ROOT, "modeling", "layers"))
 
 
-class _CfgNode(dict):
-    """Minimal yacs.config.CfgNode stand-in (attribute access + merge)."""
+def _cfgnode_class():
+    # the yacs stand-in lives in the product package (it is also the product's
+    # own config class); test infrastructure may import the product, never the
+    # other way round
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from epipolar_transformers_amd.config import CfgNode
 
-    def __init__(self, init=None):
-        super().__init__()
-        object.__setattr__(self, "_frozen", False)
-        if init:
-            for k, v in init.items():
-                self[k] = _CfgNode(v) if isinstance(v, dict) and not isinstance(v, _CfgNode) else v
-
-    def __getattr__(self, name):
-        try:
-            return self[name]
-        except KeyError as exc:
-            raise AttributeError(name) from exc
-
-    def __setattr__(self, name, value):
-        if object.__getattribute__(self, "_frozen"):
-            raise AttributeError("cfg is frozen: cannot set %s" % name)
-        self[name] = value
-
-    # -- yacs surface used by the reference --------------------------------
-    def freeze(self):
-        self._set_frozen(True)
-
-    def defrost(self):
-        self._set_frozen(False)
-
-    def _set_frozen(self, flag):
-        object.__setattr__(self, "_frozen", flag)
-        for v in self.values():
-            if isinstance(v, _CfgNode):
-                v._set_frozen(flag)
-
-    def is_frozen(self):
-        return object.__getattribute__(self, "_frozen")
-
-    def clone(self):
-        return copy.deepcopy(self)
-
-    def __deepcopy__(self, memo):
-        new = _CfgNode()
-        for k, v in self.items():
-            dict.__setitem__(new, k, copy.deepcopy(v, memo))
-        return new
-
-    @staticmethod
-    def _coerce(value, like=None):
-        if isinstance(value, str):
-            try:
-                value = ast.literal_eval(value)
-            except (ValueError, SyntaxError):
-                pass
-        if isinstance(like, tuple) and isinstance(value, list):
-            value = tuple(value)
-        if isinstance(like, float) and isinstance(value, int) and not isinstance(value, bool):
-            value = float(value)
-        return value
-
-    def _merge_dict(self, other, path=""):
-        for k, v in other.items():
-            if k not in self:
-                raise KeyError("non-existent config key: %s%s" % (path, k))
-            if isinstance(self[k], _CfgNode):
-                if not isinstance(v, dict):
-                    raise TypeError("expected mapping for %s%s" % (path, k))
-                self[k]._merge_dict(v, path + k + ".")
-            else:
-                dict.__setitem__(self, k, self._coerce(v, self[k]))
-
-    def merge_from_file(self, filename):
-        import yaml
-
-        with open(filename, "r") as fh:
-            loaded = yaml.safe_load(fh) or {}
-        self._merge_dict(loaded)
-
-    def merge_from_other_cfg(self, other):
-        self._merge_dict(other)
-
-    def merge_from_list(self, opts):
-        assert len(opts) % 2 == 0, "override list must be KEY VALUE pairs"
-        for key, value in zip(opts[0::2], opts[1::2]):
-            node = self
-            parts = key.split(".")
-            for p in parts[:-1]:
-                node = node[p]
-            if parts[-1] not in node:
-                raise KeyError("non-existent config key: %s" % key)
-            dict.__setitem__(node, parts[-1], self._coerce(value, node[parts[-1]]))
+    return CfgNode
 
 
 def _stub(name, **attrs):
@@ -145,7 +61,7 @@ def install():
             import yacs.config  # noqa: F401
         except ImportError:
             yacs = _stub("yacs")
-            yacs.config = _stub("yacs.config", CfgNode=_CfgNode)
+            yacs.config = _stub("yacs.config", CfgNode=_cfgnode_class())
     for name, attrs in [
         ("cv2", dict(IMREAD_COLOR=1, IMREAD_IGNORE_ORIENTATION=128, INTER_LINEAR=1)),
         ("torchvision", {}),

@@ -1,0 +1,142 @@
+"""CPU-side checks of the product's C ABI and host logic (no GPU, no compute
+kernels launched): the library loads, exports every symbol the header declares,
+the host-side camera algebra equals the reference's, and the per-sample set-up
+code shared with the device kernels reproduces the reference's sample locations
+bit for bit (through the CPU test hook et_debug_host_sample_setup)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT, golden_cases, load_golden
+
+from epipolar_transformers_amd import _lib, build, camera, ops
+
+
+@pytest.fixture(scope="module")
+def lib():
+    build.build_library()
+    return _lib.load()
+
+
+def test_header_symbols_are_exported(lib):
+    text = open(os.path.join(ROOT, "include", "epipolar_amd.h")).read()
+    declared = set(re.findall(r"^(?:int|const char \*)\s*(et_\w+)\(", text, flags=re.M))
+    assert declared, "no declarations parsed"
+    assert declared == set(_lib.exported_symbols())
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.et_abi_version() == _lib.ET_ABI_VERSION
+
+
+def test_struct_layout_matches_header():
+    text = open(os.path.join(ROOT, "include", "epipolar_amd.h")).read()
+    body = text[text.index("typedef struct EtLayerDesc {"):text.index("} EtLayerDesc;")]
+    names = []
+    for line in body.splitlines()[1:]:
+        line = line.split("/*")[0].strip()
+        m = re.match(r"(int32_t|float)\s+([\w\s,]+);", line)
+        if m:
+            names += [n.strip() for n in m.group(2).split(",")]
+    assert names == [f[0] for f in _lib.EtLayerDesc._fields_]
+    assert ctypes.sizeof(_lib.EtLayerDesc) == 4 * len(names)
+
+
+def test_validation_errors_are_reported(lib):
+    d = ops.LayerSpec(H=8, W=8, K=8).desc(N=1, C=6)          # C not a multiple of 4
+    rc = lib.et_epipolar_forward(ctypes.byref(d), *[ctypes.c_void_p(0)] * 10)
+    assert rc != 0 and b"multiple of 4" in lib.et_last_error()
+    d = ops.LayerSpec(H=8, W=8, K=8).desc(N=1, C=8)
+    rc = lib.et_epipolar_forward(ctypes.byref(d), *[ctypes.c_void_p(0)] * 10)
+    assert rc != 0 and b"NULL" in lib.et_last_error()
+
+
+def test_cpu_tensors_are_rejected_not_silently_computed():
+    spec = ops.LayerSpec(H=8, W=8, K=8)
+    x = torch.zeros(1, 8, 8, 8)
+    with pytest.raises(_lib.EpipolarAmdError):
+        ops.forward_nhwc(spec, x, x, torch.zeros(1, 27))
+
+
+@pytest.mark.parametrize("case", golden_cases())
+def test_camera_algebra_equals_reference_loop(oracle_mod, case):
+    d = load_golden(case)
+    P1, P2 = torch.from_numpy(d["P1"]), torch.from_numpy(d["P2"])
+    cam = camera.pair_algebra(P1, P2).numpy()
+    a, b, c = oracle_mod.camera_algebra(P1, P2)      # per-matrix pinverse loop, as epipolar.py:336
+    assert np.array_equal(cam[:, :12], a.reshape(-1, 12))
+    assert np.array_equal(cam[:, 12:24], b.reshape(-1, 12))
+    assert np.array_equal(cam[:, 24:], c)
+
+
+def _spec_from_golden(d, **kw):
+    m = d["dims"]
+    return ops.LayerSpec(H=m["H"], W=m["W"], K=m["K"], downsample=float(d["downsample"]),
+                         correct_normalize=m["correct"], softmax_scale=float(d["softmax_scale"]),
+                         softmax_enabled=m["softmax"], **kw)
+
+
+@pytest.mark.parametrize("case", golden_cases())
+def test_device_setup_code_reproduces_reference_sample_locs(lib, case):
+    d = load_golden(case)
+    spec = _spec_from_golden(d)
+    m = d["dims"]
+    cam = camera.pair_algebra(torch.from_numpy(d["P1"]), torch.from_numpy(d["P2"])).numpy()
+    desc = spec.desc(m["N"], m["C"])
+    K, W = m["K"], m["W"]
+    taps = np.zeros((K, 4), np.int32)
+    wts = np.zeros((K, 4), np.float32)
+    locs = np.zeros((K, 2), np.float32)
+    xs, ys, steps = spec.xs.numpy(), spec.ys.numpy(), spec.steps.numpy()
+    fp = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+    rng = np.random.default_rng(0)
+    for n in range(m["N"]):
+        camn = np.ascontiguousarray(cam[n])
+        for ri, h in enumerate(d["rows"]):
+            for w in rng.choice(W, size=min(W, 6), replace=False):
+                rc = lib.et_debug_host_sample_setup(ctypes.byref(desc), fp(xs), fp(ys), fp(steps), fp(camn),
+                                                    int(h), int(w), fp(taps), fp(wts), fp(locs))
+                assert rc == 0, lib.et_last_error()
+                want = d["sample_locs"][:, n, ri, w]                 # (K,2) from the real reference
+                assert np.array_equal(locs, want), (n, h, w)
+                # taps / weights against the textbook bilinear rule on those locations
+                gx = (want[:, 0] + 1) * np.float32(W / 2) - np.float32(0.5)
+                gy = (want[:, 1] + 1) * np.float32(m["H"] / 2) - np.float32(0.5)
+                x0, y0 = np.floor(gx), np.floor(gy)
+                fx, fy = gx - x0, gy - y0
+                for k in range(K):
+                    seen = {}
+                    for r in range(4):
+                        if taps[k, r] >= 0:
+                            ty, tx = divmod(int(taps[k, r]), W)
+                            assert (ty & 1, tx & 1) == (r >> 1, r & 1)            # parity routing
+                            seen[(tx - int(x0[k]), ty - int(y0[k]))] = wts[k, r]
+                        else:
+                            assert wts[k, r] == 0
+                    for (dx, dy), wv in seen.items():
+                        assert dx in (0, 1) and dy in (0, 1)
+                        wx = fx[k] if dx else np.float32(1) - fx[k]
+                        wy = fy[k] if dy else np.float32(1) - fy[k]
+                        assert wv == np.float32(wy * wx)
+                    # every in-image tap of the 2x2 footprint is present
+                    for dx in (0, 1):
+                        for dy in (0, 1):
+                            xx, yy = int(x0[k]) + dx, int(y0[k]) + dy
+                            if 0 <= xx < W and 0 <= yy < m["H"] and abs(x0[k]) < 1e6:
+                                assert (dx, dy) in seen
+
+
+def test_layerspec_constants_match_reference_constructor():
+    # epipolar.py:35-54 for the headline config: 4*x+1.5 grid, inclusive torch.range steps
+    spec = ops.LayerSpec(H=64, W=64, K=64)
+    assert spec.xs[0] == 1.5 and spec.xs[-1] == 253.5 and spec.ys[3] == 13.5
+    assert spec.steps[0] == 0 and spec.steps[-1] == 1 and len(spec.steps) == 64
+    import warnings
+
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        ref = torch.range(0, 1, 1.0 / 63)
+    assert torch.equal(ref, spec.steps)
