@@ -1,0 +1,218 @@
+#!/usr/bin/env python
+"""Benchmark of the Epipolar Transformer hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W [--partition frames|views]
+
+One "step" = one pass of the whole layer over
+one synthetic batch of BASELINE.json configs[1]: H36M 4 views x 32 frames =
+128 (reference, source) pairs per GPU, ResNet-50 head (C=256, 64x64), K=64,
+`configs/epipolar/keypoint_h36m_zresidual_fixed.yaml` semantics:
+  host camera algebra (float32, per step, no caching) -> fused HIP
+  sample+attention kernel -> 1x1 conv z (GEMM) -> fused BN/residual epilogue.
+Feature maps are resident in HBM (channels-last, as the pose backbone emits
+them) when the timed region starts.  `value` is whole-job pair-views per second.
+
+Multi-GPU (one process per GPU, torch.distributed / RCCL):
+  --partition frames (default): every rank owns whole frames, all views local,
+      no data-path collective -> weak scaling.
+  --partition views: rank r owns camera r mod V for its frames; the source-view
+      feature maps are exchanged with an RCCL all-gather inside the timed step
+      (the north-star partition; see DESIGN.md "Multi-GPU").
+Rank 0 prints ONE JSON line.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+import torch.nn.functional as F
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec (MI355X_MICROARCH.md)
+FP32_PEAK_TFLOPS = 157.3     # fp32 vector peak (same file)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--partition", choices=["frames", "views"], default="frames")
+    ap.add_argument("--frames", type=int, default=32, help="frames per GPU (4 views each)")
+    ap.add_argument("--views", type=int, default=4)
+    ap.add_argument("--hw", type=int, default=64)
+    ap.add_argument("--channels", type=int, default=256)
+    ap.add_argument("--samples", type=int, default=64)
+    ap.add_argument("--variant", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-pairs", type=int, default=8, help="pairs in the bounded CPU-baseline sample")
+    return ap.parse_args()
+
+
+def algorithmic_bytes_per_pair(C, H, W, K):
+    """read feat_ref + feat_src, write out, attn, corr_pos, two 3x4 P."""
+    return 3 * C * H * W * 4 + K * H * W * 4 + H * W * 8 + 96
+
+
+def algorithmic_flops_per_pair(C, H, W, K):
+    return 12 * K * C * H * W
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+    assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
+
+    from epipolar_transformers_amd import _lib, camera, ops, synthetic as syn
+    from epipolar_transformers_amd.parallel import ViewShardExchange
+
+    _lib.load()
+    H = W = args.hw
+    C, K, V = args.channels, args.samples, args.views
+    image = H * 4
+    spec = ops.LayerSpec(H=H, W=W, K=K, variant=args.variant)
+
+    # ---- this rank's pairs -----------------------------------------------------------
+    frames = args.frames
+    P_ref, P_src = syn.make_pairs(frames, V, image, seed=1000 + rank, jitter=(0.05, 8.0))
+    n_pairs = P_ref.shape[0]                                      # frames * views
+    exchange = None
+    g = torch.Generator(device=dev).manual_seed(rank)
+    if args.partition == "views" and world > 1:
+        # rank owns `n_pairs` reference maps of ONE camera (or V/world cameras); sources arrive by all-gather
+        exchange = ViewShardExchange(world, rank, V)
+        P_ref, P_src = exchange.select_pairs(frames * V, image, seed=1000)
+        n_pairs = P_ref.shape[0]
+    feat_ref = torch.randn(n_pairs, H, W, C, device=dev, generator=g).relu_()      # NHWC, post-ReLU statistics
+    feat_own = feat_ref                                                            # maps this rank produced
+    feat_src = torch.randn(n_pairs, H, W, C, device=dev, generator=g).relu_() if exchange is None else None
+    z_w = (torch.randn(C, C, 1, 1, device=dev, generator=g) * 0.05).contiguous(memory_format=torch.channels_last)
+    z_b = torch.randn(C, device=dev, generator=g) * 0.1
+    bn_scale = (1 + 0.1 * torch.randn(C, device=dev, generator=g)).contiguous()
+    bn_shift = (0.1 * torch.randn(C, device=dev, generator=g)).contiguous()
+    P_ref_pin, P_src_pin = P_ref.pin_memory(), P_src.pin_memory()
+
+    def layer_step():
+        cam = camera.pair_algebra(P_ref_pin, P_src_pin).pin_memory().to(dev, non_blocking=True)
+        src = feat_src if exchange is None else exchange.gather_sources(feat_own)
+        out, attn, corr = ops.forward_nhwc(spec, feat_ref, src, cam)
+        y = F.conv2d(out.permute(0, 3, 1, 2), z_w, z_b).permute(0, 2, 3, 1)        # z: 1x1 conv == GEMM
+        fin, x = ops.residual_epilogue(feat_ref, out, y, bn_scale, bn_shift, False, True)
+        return x, attn, corr
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        layer_step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        layer_step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    ms_per_step = elapsed / args.steps * 1e3
+    value = n_pairs * world * args.steps / elapsed
+
+    # ---- roofline of the dominant kernel: HIP events on the launch stream -----------------
+    cam = camera.pair_algebra(P_ref, P_src).to(dev)
+    src = feat_src if exchange is None else exchange.gather_sources(feat_own)
+    reps = max(5, min(args.steps, 30))
+    for _ in range(3):
+        ops.forward_nhwc(spec, feat_ref, src, cam)
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+    torch.cuda.synchronize()
+    for a, b in ev:
+        a.record()
+        ops.forward_nhwc(spec, feat_ref, src, cam)
+        b.record()
+    torch.cuda.synchronize()
+    k_ms = sorted(a.elapsed_time(b) for a, b in ev)
+    kernel_ms = sum(k_ms) / len(k_ms)
+    bytes_launch = algorithmic_bytes_per_pair(C, H, W, K) * n_pairs
+    flops_launch = algorithmic_flops_per_pair(C, H, W, K) * n_pairs
+    achieved_gbs = bytes_launch / (kernel_ms * 1e-3) / 1e9
+    achieved_tf = flops_launch / (kernel_ms * 1e-3) / 1e12
+
+    # fwd + bwd of the fused kernel (extra information, not the headline metric)
+    gout = torch.randn_like(feat_ref)
+    for _ in range(2):
+        ops.backward_nhwc(spec, feat_ref, src, cam, gout)
+    torch.cuda.synchronize()
+    tb = time.perf_counter()
+    nb = 5
+    for _ in range(nb):
+        ops.backward_nhwc(spec, feat_ref, src, cam, gout)
+    torch.cuda.synchronize()
+    bwd_ms = (time.perf_counter() - tb) / nb * 1e3
+
+    result = {
+        "metric": "multi-view images/sec at H36M 4-view 256x256 bs=32 (pair-views/s, whole layer forward)",
+        "value": value, "unit": "pair-views/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "configs[1]: epipolarposeR-50 head, 4 views x %d frames = %d pairs/GPU, C=%d, %dx%d, K=%d, "
+                               "z+BN+residual, eval" % (frames, n_pairs, C, H, W, K),
+                   "partition": args.partition, "layout": "NHWC (channels_last)", "pairs_per_gpu": n_pairs,
+                   "variant": args.variant},
+        "roofline": {"bound": "hbm", "kernel": "epipolar_fwd_kernel", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS,
+                     "unit": "GB/s", "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": None,
+                     "kernel_ms": kernel_ms, "kernel_ms_min": k_ms[0], "algorithmic_bytes_per_launch": bytes_launch,
+                     "valu": {"achieved": achieved_tf, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                              "frac": achieved_tf / FP32_PEAK_TFLOPS, "algorithmic_flops_per_launch": flops_launch}},
+        "extra": {"fused_kernel_fwd_ms": kernel_ms, "fused_kernel_bwd_ms": bwd_ms,
+                  "kernel_only_pair_views_per_s": n_pairs / (kernel_ms * 1e-3)},
+    }
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        result["cpu_baseline"] = cpu_baseline(args, spec, feat_ref, src, P_ref, P_src)
+    if rank == 0:
+        print(json.dumps(result))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(args, spec, feat_ref, feat_src, P_ref, P_src):
+    """The CPU oracle (a port of the reference algorithm, OpenMP over pixels)
+    timed on this box's host cores on a bounded sample of the same workload."""
+    from oracle import oracle as orc
+
+    orc.build()
+    n = min(args.cpu_pairs, feat_ref.shape[0])
+    f1 = feat_ref[:n].permute(0, 3, 1, 2).contiguous().cpu().numpy()
+    f2 = feat_src[:n].permute(0, 3, 1, 2).contiguous().cpu().numpy()
+    ospec = orc.LayerSpec(spec.H, spec.W, spec.K)
+    cores = os.cpu_count() or 1
+    orc.forward_fused_timed(ospec, f1[:1], f2[:1], P_ref[:1], P_src[:1])        # warm-up
+    t0 = time.perf_counter()
+    orc.forward_fused_timed(ospec, f1, f2, P_ref[:n], P_src[:n])
+    dt = time.perf_counter() - t0
+    return {"value": n / dt, "unit": "pair-views/s", "cores": cores, "kind": "port",
+            "sample": "%d of the %d pairs of one GPU's batch, fused sample+attention only (no z/BN), "
+                      "oracle/epipolar_oracle.c with OpenMP on %d threads, %.2f s" % (n, feat_ref.shape[0], cores, dt)}
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,277 @@
+"""Parity of the HIP path (called through the C ABI) against
+  (1) the golden vectors produced by the real reference, and
+  (2) the CPU oracle on seeded inputs, up to BASELINE.json's full shape.
+
+Tolerances (BASELINE.json north_star / SURVEY.md section 8c, float32):
+  sample_locs <= 1e-5 (normalised units; measured 0), attn <= 1e-5,
+  out / fused x <= 1e-4 absolute, corr_pos exact except at float ties,
+  gradients <= 1e-4 relative to the tensor's max magnitude.
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden_cases, load_golden
+
+pytestmark = pytest.mark.gpu
+
+TOL_LOCS, TOL_ATTN, TOL_OUT, TOL_GRAD_REL = 1e-5, 1e-5, 1e-4, 1e-4
+
+
+@pytest.fixture(scope="module")
+def env():
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    from epipolar_transformers_amd import _lib, camera, ops
+
+    _lib.load()
+    return _lib, camera, ops
+
+
+def _spec(ops, d, **kw):
+    m = d["dims"]
+    return ops.LayerSpec(H=m["H"], W=m["W"], K=m["K"], downsample=float(d["downsample"]),
+                         correct_normalize=m["correct"], softmax_scale=float(d["softmax_scale"]),
+                         softmax_enabled=m["softmax"], **kw)
+
+
+def _dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def _run_forward(env, d, variant=0):
+    _lib, camera, ops = env
+    spec = _spec(ops, d, variant=variant)
+    cam = camera.pair_algebra(torch.from_numpy(d["P1"]), torch.from_numpy(d["P2"])).cuda()
+    ref = ops.to_nhwc(_dev(d["feat1"]))
+    src = ops.to_nhwc(_dev(d["feat2"]))
+    out, attn, corr = ops.forward_nhwc(spec, ref, src, cam)
+    torch.cuda.synchronize()
+    return spec, cam, ref, src, out.permute(0, 3, 1, 2).cpu().numpy(), attn.cpu().numpy(), corr.cpu().numpy()
+
+
+def _close(got, want, atol, rtol=2e-6):
+    err = np.abs(got - want) - rtol * np.abs(want)
+    assert err.max() <= atol, "max|d|=%g (scale %g)" % (np.abs(got - want).max(), np.abs(want).max())
+
+
+@pytest.mark.parametrize("case", golden_cases())
+def test_sample_locs_vs_reference(env, case):
+    _lib, camera, ops = env
+    d = load_golden(case)
+    spec = _spec(ops, d)
+    cam = camera.pair_algebra(torch.from_numpy(d["P1"]), torch.from_numpy(d["P2"])).cuda()
+    locs = ops.sample_locs(spec, cam).cpu().numpy()[:, :, d["rows"]]
+    assert np.abs(locs - d["sample_locs"]).max() <= TOL_LOCS
+    # the device evaluates the same IEEE float32 expression tree: expect bit equality
+    assert np.array_equal(locs, d["sample_locs"])
+
+
+@pytest.mark.parametrize("variant", [0, 1, 2, 3])
+@pytest.mark.parametrize("case", golden_cases())
+def test_forward_vs_reference(env, case, variant):
+    d = load_golden(case)
+    _, _, _, _, out, attn, corr = _run_forward(env, d, variant)
+    _close(attn[:, :, d["rows"]], d["attn"], TOL_ATTN)
+    _close(out, d["out"], TOL_OUT)
+    neq = (corr != d["corr_pos"]).any(-1)
+    assert neq.mean() <= 5e-3, "corr_pos mismatches: %g" % neq.mean()
+
+
+@pytest.mark.parametrize("case", golden_cases())
+def test_forward_vs_oracle_full_tensors(env, oracle_mod, case):
+    d = load_golden(case)
+    m = d["dims"]
+    spec_o = oracle_mod.LayerSpec(m["H"], m["W"], m["K"], downsample=float(d["downsample"]),
+                                  correct_normalize=m["correct"], softmax_scale=float(d["softmax_scale"]),
+                                  softmax_enabled=m["softmax"])
+    want = oracle_mod.forward(spec_o, d["feat1"], d["feat2"], torch.from_numpy(d["P1"]), torch.from_numpy(d["P2"]))
+    _, _, _, _, out, attn, corr = _run_forward(env, d)
+    _close(attn, want["attn"], TOL_ATTN)
+    _close(out, want["out"], TOL_OUT)
+    assert ((corr != want["corr_pos"]).any(-1)).mean() <= 5e-3
+
+
+@pytest.mark.parametrize("case", golden_cases())
+def test_zero_feature_pixel_uniform_attention(env, case):
+    d = load_golden(case)
+    if not (d["feat1"][0, :, 3, 5] == 0).all() or not d["dims"]["softmax"]:
+        pytest.skip("no all-zero reference pixel in this case")
+    _, _, _, _, out, attn, _ = _run_forward(env, d)
+    assert np.allclose(attn[0, :, 3, 5], 1.0 / d["dims"]["K"], atol=1e-7)       # epipolar.py:298 (H3)
+
+
+@pytest.mark.parametrize("variant", [0, 1])
+@pytest.mark.parametrize("case", golden_cases())
+def test_backward_vs_reference_autograd(env, case, variant):
+    _lib, camera, ops = env
+    d = load_golden(case)
+    spec, cam, ref, src, _, _, _ = _run_forward(env, d, variant)
+    g = ops.to_nhwc(_dev(d["grad_out"]))
+    g_ref, g_src = ops.backward_nhwc(spec, ref, src, cam, g)
+    torch.cuda.synchronize()
+    for got, want in ((g_ref, d["grad_feat1"]), (g_src, d["grad_feat2"])):
+        got = got.permute(0, 3, 1, 2).cpu().numpy()
+        scale = np.abs(want).max()
+        assert np.abs(got - want).max() <= TOL_GRAD_REL * scale, (np.abs(got - want).max(), scale)
+
+
+@pytest.mark.parametrize("case", golden_cases())
+def test_backward_other_grad_masks_sum_to_full(env, case):
+    """OTHER_GRAD (epipolar.py:141-153): the similarity-path and value-path
+    gradients of feat_src add up to the full one."""
+    _lib, camera, ops = env
+    d = load_golden(case)
+    spec, cam, ref, src, _, _, _ = _run_forward(env, d)
+    g = ops.to_nhwc(_dev(d["grad_out"]))
+    parts = []
+    for mask in (3, 1, 2, 0):
+        spec.src_grad_mask = mask
+        g_ref, g_src = ops.backward_nhwc(spec, ref, src, cam, g)
+        parts.append((g_ref.cpu().numpy(), g_src.cpu().numpy()))
+    full, sim_only, val_only, none = parts
+    scale = np.abs(full[1]).max()
+    assert np.abs(sim_only[1] + val_only[1] - full[1]).max() <= 1e-5 * scale
+    assert np.abs(none[1]).max() == 0
+    for p in parts[1:]:
+        assert np.abs(p[0] - full[0]).max() <= 1e-6 * max(1.0, np.abs(full[0]).max())   # d(feat_ref) never masked
+
+
+@pytest.mark.parametrize("case", golden_cases())
+def test_module_dropin_eval_and_train(env, case):
+    """The nn.Module boundary: same ctor/forward/returns/state_dict keys as the
+    reference operator; eval mode uses the fused epilogue kernel, train mode
+    batch statistics."""
+    from epipolar_transformers_amd import default_cfg
+    from epipolar_transformers_amd.epipolar import Epipolar
+
+    d = load_golden(case)
+    m = d["dims"]
+    cfg = default_cfg()
+    cfg.merge_from_list(["KEYPOINT.HEATMAP_SIZE", (m["H"], m["W"]), "KEYPOINT.NFEATS", m["C"],
+                         "EPIPOLAR.SAMPLESIZE", m["K"], "EPIPOLAR.ATTENTION", "avg",
+                         "EPIPOLAR.PARAMETERIZED", ("z",), "EPIPOLAR.ZRESIDUAL", True,
+                         "EPIPOLAR.USE_CORRECT_NORMALIZE", m["correct"], "EPIPOLAR.SOFTMAX_ENABLED", m["softmax"],
+                         "EPIPOLAR.SOFTMAXSCALE", float(d["softmax_scale"]), "VIS.EPIPOLAR_LINE", True])
+    mod = Epipolar(cfg=cfg).cuda()
+    assert sorted(mod.state_dict()) == sorted(["z.weight", "z.bias", "bn.weight", "bn.bias", "bn.running_mean",
+                                               "bn.running_var", "bn.num_batches_tracked"])
+    sd = {"z.weight": d["z_weight"], "z.bias": d["z_bias"], "bn.weight": d["bn_weight"], "bn.bias": d["bn_bias"],
+          "bn.running_mean": d["bn_running_mean"], "bn.running_var": d["bn_running_var"]}
+    mod.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=False)
+    f1, f2 = _dev(d["feat1"]), _dev(d["feat2"])
+    P1, P2 = torch.from_numpy(d["P1"]), torch.from_numpy(d["P2"])       # host-resident, as the loader yields them
+    mod.eval()
+    with torch.no_grad():
+        fin, corr, depth, locs = mod(f1, f2, P1, P2)
+        x, _, _, _ = mod.forward_fused(f1, f2, P1.cuda(), P2.cuda())   # device-resident P also accepted
+    assert tuple(fin.shape) == d["finalout_eval"].shape and tuple(depth.shape) == (m["N"], m["K"], m["H"], m["W"])
+    assert tuple(corr.shape) == (m["N"], m["H"], m["W"], 2) and tuple(locs.shape) == (m["N"], m["K"], m["H"], m["W"], 2)
+    _close(fin.cpu().numpy(), d["finalout_eval"], TOL_OUT)
+    _close(x.cpu().numpy(), d["finalout_eval"] + d["feat1"], TOL_OUT)     # resnet.py:388
+    assert np.array_equal(locs.cpu().numpy().transpose(1, 0, 2, 3, 4)[:, :, d["rows"]], d["sample_locs"])
+    mod.train()
+    with torch.no_grad():
+        fin_t, _, _, _ = mod(f1, f2, P1, P2)
+    _close(fin_t.cpu().numpy(), d["finalout_train"], TOL_OUT, rtol=1e-5)
+    _close(mod.bn.running_mean.cpu().numpy(), d["bn_running_mean_after"], 1e-5)
+    _close(mod.bn.running_var.cpu().numpy(), d["bn_running_var_after"], 1e-5)
+    # autograd through the module (train mode), gradients of sum(out * grad_out) w.r.t. both maps
+    a1, a2 = f1.clone().requires_grad_(True), f2.clone().requires_grad_(True)
+    out, _, _ = mod.attend(a1, a2, P1, P2)
+    (out * _dev(d["grad_out"])).sum().backward()
+    for got, want in ((a1.grad, d["grad_feat1"]), (a2.grad, d["grad_feat2"])):
+        scale = np.abs(want).max()
+        assert np.abs(got.cpu().numpy() - want).max() <= TOL_GRAD_REL * scale
+
+
+def test_layout_converters_roundtrip(env):
+    _lib, camera, ops = env
+    x = torch.randn(3, 20, 7, 9, device="cuda")
+    nhwc = ops.to_nhwc(x)
+    assert torch.equal(nhwc, x.permute(0, 2, 3, 1).contiguous())
+    assert torch.equal(ops.to_nchw_contiguous(nhwc), x)
+    cl = x.contiguous(memory_format=torch.channels_last)
+    assert ops.to_nhwc(cl).data_ptr() == cl.data_ptr()          # zero-copy for channels_last producers
+
+
+# ---------------------------------------------------------------------------------------
+# BASELINE.json shapes
+# ---------------------------------------------------------------------------------------
+def _full_inputs(frames, views, H, C, image, seed):
+    from epipolar_transformers_amd import synthetic as syn
+
+    P1, P2 = syn.make_pairs(frames, views, image, seed=seed, jitter=(0.05, 8.0))
+    f1, f2 = syn.make_features(P1.shape[0], C, H, H, seed=seed)
+    return P1, P2, f1, f2
+
+
+@pytest.mark.parametrize("shape", [dict(H=64, C=256, K=64, image=256, views=4, name="config2 R50 256x256"),
+                                   dict(H=96, C=256, K=64, image=384, views=4, name="config4 R152 384x384"),
+                                   dict(H=128, C=256, K=128, image=512, views=8, name="config5 stress")])
+def test_full_shape_pairs_vs_oracle(env, oracle_mod, shape):
+    """BASELINE.json configs 2/4/5 at their real C, HxW and K, on a few pairs the
+    oracle finishes in seconds (full tensors compared)."""
+    _lib, camera, ops = env
+    H, C, K = shape["H"], shape["C"], shape["K"]
+    P1, P2, f1, f2 = _full_inputs(1, shape["views"], H, C, shape["image"], seed=11)
+    P1, P2, f1, f2 = P1[:2], P2[:2], f1[:2], f2[:2]
+    f1[0, :, 5, 7] = 0
+    spec = ops.LayerSpec(H=H, W=H, K=K)
+    cam = camera.pair_algebra(P1, P2).cuda()
+    ref, src = ops.to_nhwc(f1.cuda()), ops.to_nhwc(f2.cuda())
+    out, attn, corr = ops.forward_nhwc(spec, ref, src, cam)
+    want = oracle_mod.forward(oracle_mod.LayerSpec(H, H, K), f1, f2, P1, P2)
+    _close(attn.cpu().numpy(), want["attn"], TOL_ATTN)
+    _close(out.permute(0, 3, 1, 2).cpu().numpy(), want["out"], TOL_OUT)
+    assert ((corr.cpu().numpy() != want["corr_pos"]).any(-1)).mean() <= 5e-3
+    locs = ops.sample_locs(spec, cam).cpu().numpy()
+    assert np.array_equal(locs, want["sample_locs"])
+    # gradients at full C on one pair
+    g = torch.randn(1, C, H, H, generator=torch.Generator().manual_seed(5))
+    g1, g2 = oracle_mod.backward(oracle_mod.LayerSpec(H, H, K), f1[:1].numpy(), f2[:1].numpy(),
+                                 want["sample_locs"][:, :1], g.numpy())
+    spec1 = ops.LayerSpec(H=H, W=H, K=K)
+    gr, gs = ops.backward_nhwc(spec1, ref[:1].contiguous(), src[:1].contiguous(), cam[:1].contiguous(),
+                               ops.to_nhwc(g.cuda()))
+    for got, wantg in ((gr, g1), (gs, g2)):
+        scale = np.abs(wantg).max()
+        assert np.abs(got.permute(0, 3, 1, 2).cpu().numpy() - wantg).max() <= TOL_GRAD_REL * scale
+
+
+def test_config2_full_batch_properties(env):
+    """Config 2 at its full size (N=128, C=256, 64x64, K=64): size-independent
+    properties instead of an oracle run."""
+    _lib, camera, ops = env
+    P1, P2, f1, f2 = _full_inputs(32, 4, 64, 256, 256, seed=0)
+    spec = ops.LayerSpec(H=64, W=64, K=64)
+    cam = camera.pair_algebra(P1, P2).cuda()
+    ref, src = ops.to_nhwc(f1.cuda()), ops.to_nhwc(f2.cuda())
+    out, attn, corr = ops.forward_nhwc(spec, ref, src, cam)
+    # (1) soft-max rows sum to one
+    assert (attn.sum(1) - 1).abs().max().item() < 1e-5
+    # (2) determinism: the forward has no atomics, a second launch is bit-identical
+    out2, attn2, corr2 = ops.forward_nhwc(spec, ref, src, cam)
+    assert torch.equal(out, out2) and torch.equal(attn, attn2) and torch.equal(corr, corr2)
+    # (3) all variants agree
+    for v in (1, 2, 3):
+        spec_v = ops.LayerSpec(H=64, W=64, K=64, variant=v)
+        out_v, attn_v, _ = ops.forward_nhwc(spec_v, ref, src, cam)
+        assert (out_v - out).abs().max().item() <= 1e-5 and (attn_v - attn).abs().max().item() <= 1e-6
+    # (4) a constant source map is reproduced wherever the whole segment is interior:
+    #     out = sum_k a_k * 1 = 1 ; elsewhere out <= 1 (zero padding only removes mass)
+    ones = torch.ones_like(src)
+    out1, attn1, _ = ops.forward_nhwc(spec, ref, ones, cam)
+    assert out1.max().item() <= 1 + 1e-5 and out1.min().item() >= 0
+    locs = ops.sample_locs(spec, cam[:8].contiguous())
+    interior = (locs.abs().amax(-1).amax(0) < 0.95)                      # (8,H,W) every sample well inside
+    assert interior.float().mean().item() > 0.3
+    sel = out1[:8][interior]
+    assert (sel - 1).abs().max().item() < 1e-5
+    # (5) out is linear in the VALUE role of feat_src for fixed attention: scaling the source by 2
+    #     with logits compensated (feat_ref / 2) doubles the output exactly (power of two)
+    out_s, attn_s, _ = ops.forward_nhwc(spec, (ref * 0.5).contiguous(), (src * 2).contiguous(), cam)
+    assert torch.equal(attn_s, attn) and torch.equal(out_s, out * 2)
+    # (6) checksum of checksums vs the per-pair launches (batching must not change a pair's result)
+    sub = slice(40, 44)
+    out_p, attn_p, _ = ops.forward_nhwc(spec, ref[sub].contiguous(), src[sub].contiguous(), cam[sub].contiguous())
+    assert torch.equal(out_p, out[sub]) and torch.equal(attn_p, attn[sub])

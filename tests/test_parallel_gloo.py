@@ -1,0 +1,91 @@
+"""Multi-process CPU tests (gloo) of the two multi-GPU partitions.  The tensors
+are CPU stand-ins; what is under test is the sharding/exchange logic that the
+RCCL path runs unchanged on the GPUs."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from epipolar_transformers_amd.parallel import ViewShardExchange, frames_partition
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _global_map(frame, view, shape=(2, 3, 4)):
+    return torch.full(shape, float(frame * 10 + view))
+
+
+def _worker(rank, world, port, V, frames, errs):
+    try:
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        ex = ViewShardExchange(world, rank, V)
+        P_ref, P_src = ex.select_pairs(frames * V, 64, seed=3)
+        assert P_ref.shape[0] == len(ex.my_cams) * frames
+        fr0 = ex.slice_id * frames                       # global frame ids of this slice
+        own = torch.stack([_global_map(fr0 + f, v) for v in ex.my_cams for f in range(frames)])
+        src = ex.gather_sources(own)
+        want = torch.stack([_global_map(fr0 + f, (v + 1) % V) for v in ex.my_cams for f in range(frames)])
+        assert torch.equal(src, want), "rank %d got wrong source maps" % rank
+        # projection matrices follow the same pairing: the source matrix of (frame, v) is the
+        # reference matrix of camera (v+1) % V of the same frame
+        allref = [torch.empty_like(P_ref) for _ in ex.group_ranks]
+        dist.all_gather(allref, P_ref, group=ex._pg())
+        for ci, v in enumerate(ex.my_cams):
+            owner, idx = ex.source_location(v)
+            got = allref[ex.group_ranks.index(owner)][idx * frames:(idx + 1) * frames]
+            assert torch.equal(got, P_src[ci * frames:(ci + 1) * frames])
+        # backward routing: gradient w.r.t. the gathered sources returns to the owning rank
+        g = torch.stack([_global_map(fr0 + f, v) + 0.5 for v in ex.my_cams for f in range(frames)])
+        back = ex.scatter_source_grads(g)
+        # own map of camera c is the source of reference camera (c-1) % V
+        want_b = torch.stack([_global_map(fr0 + f, (c - 1) % V) + 0.5 for c in ex.my_cams for f in range(frames)])
+        assert torch.equal(back, want_b), "rank %d got wrong source gradients" % rank
+        dist.barrier()
+        dist.destroy_process_group()
+    except Exception as exc:  # pragma: no cover - surfaced in the parent
+        errs.put("rank %d: %r" % (rank, exc))
+        raise
+
+
+@pytest.mark.parametrize("world,V", [(2, 4), (4, 4), (2, 8)])
+def test_view_sharded_exchange_gloo(world, V):
+    ctx = mp.get_context("spawn")
+    errs = ctx.SimpleQueue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, V, 3, errs)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(180)
+    msgs = []
+    while not errs.empty():
+        msgs.append(errs.get())
+    assert not msgs, msgs
+    assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+
+
+def test_view_sharded_layout_world8_views4():
+    # two ranks per camera: groups of 4 ranks exchange among themselves
+    for rank in range(8):
+        ex = ViewShardExchange(8, rank, 4)
+        assert ex.my_cams == [rank % 4] and ex.slice_id == rank // 4
+        owner, idx = ex.source_location(rank % 4)
+        assert owner == (rank // 4) * 4 + (rank % 4 + 1) % 4 and idx == 0
+
+
+def test_frames_partition_covers_everything():
+    for frames in (1, 7, 32, 33):
+        for world in (1, 2, 3, 8):
+            spans = [frames_partition(frames, world, r) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == frames
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            sizes = [b - a for a, b in spans]
+            assert max(sizes) - min(sizes) <= 1
