@@ -56,7 +56,6 @@ constexpr int kWave = 64;
 constexpr int kWavesPerBlock = 4;
 constexpr int kPixPerWave = 4;
 constexpr int kPixPerBlock = kWavesPerBlock * kPixPerWave;  // 16 consecutive pixels
-constexpr int kBatch = 8;
 constexpr int kXcds = 8;
 
 struct FwdParams {
@@ -66,6 +65,7 @@ struct FwdParams {
     float *out, *attn, *corr;
     int blocks_per_pair;
     int total_blocks;
+    int interleave;
 };
 
 struct BwdParams {
@@ -115,7 +115,7 @@ __device__ __forceinline__ float xstep_safe(float a, float b, int lane, int bit)
 // group g = lane >> 3 holds (replicated) the total of partial j = bitrev3(g),
 // i.e. j = ((lane >> 5) & 1) | ((lane >> 4) & 1) << 1 | ((lane >> 3) & 1) << 2.
 template <bool FAST>
-__device__ __forceinline__ float reduce8(const float (&p)[kBatch], int lane)
+__device__ __forceinline__ float reduce8(const float (&p)[8], int lane)
 {
     if constexpr (FAST) {
         float q[4];
@@ -157,10 +157,58 @@ __device__ __forceinline__ float reduce8(const float (&p)[kBatch], int lane)
     }
 }
 
-// lane that holds batch sample j after reduce8
+// Four-partial variant: the 16-lane row r = lane >> 4 holds the total of partial
+// j = ((lane >> 5) & 1) | ((lane >> 4) & 1) << 1.
+template <bool FAST>
+__device__ __forceinline__ float reduce4(const float (&p)[4], int lane)
+{
+    if constexpr (FAST) {
+        float q[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(p[2 * i]), __float_as_uint(p[2 * i + 1]),
+                                                      false, false);
+            q[i] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+        }
+        auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(q[0]), __float_as_uint(q[1]), false, false);
+        float u = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+        u += dpp<0x128>(u);  // row_ror:8
+        u += dpp<0x124>(u);  // row_ror:4
+        u += dpp<0x122>(u);  // row_ror:2
+        u += dpp<0x121>(u);  // row_ror:1
+        return u;
+    } else {
+        const float q0 = xstep_safe(p[0], p[1], lane, 32);
+        const float q1 = xstep_safe(p[2], p[3], lane, 32);
+        float u = xstep_safe(q0, q1, lane, 16);
+        u += __shfl_xor(u, 8);
+        u += __shfl_xor(u, 4);
+        u += __shfl_xor(u, 2);
+        u += __shfl_xor(u, 1);
+        return u;
+    }
+}
+
+template <int BATCH, bool FAST>
+__device__ __forceinline__ float reduce_batch(const float (&p)[BATCH], int lane)
+{
+    static_assert(BATCH == 4 || BATCH == 8, "batch of 4 or 8 samples");
+    if constexpr (BATCH == 8) return reduce8<FAST>(p, lane);
+    else return reduce4<FAST>(p, lane);
+}
+
+// lane that holds batch sample j after reduce_batch, and the sample a lane holds
+template <int BATCH>
 __host__ __device__ constexpr int lane_of_sample(int j)
 {
-    return 32 * (j & 1) + 16 * ((j >> 1) & 1) + 8 * ((j >> 2) & 1);
+    return BATCH == 8 ? 32 * (j & 1) + 16 * ((j >> 1) & 1) + 8 * ((j >> 2) & 1) : 32 * (j & 1) + 16 * ((j >> 1) & 1);
+}
+
+template <int BATCH>
+__device__ __forceinline__ int sample_of_lane(int lane)
+{
+    const int j = ((lane >> 5) & 1) | (((lane >> 4) & 1) << 1);
+    return BATCH == 8 ? (j | (((lane >> 3) & 1) << 2)) : j;
 }
 
 __device__ __forceinline__ float wave_max(float v)
@@ -177,10 +225,11 @@ __device__ __forceinline__ float wave_sum(float v)
     return v;
 }
 
-// max over the eight 8-lane groups (values already uniform inside a group)
+// max over the lane groups of a batch (values already uniform inside a group)
+template <int BATCH>
 __device__ __forceinline__ float group_max(float v)
 {
-    v = fmaxf(v, __shfl_xor(v, 8));
+    if constexpr (BATCH == 8) v = fmaxf(v, __shfl_xor(v, 8));
     v = fmaxf(v, __shfl_xor(v, 16));
     v = fmaxf(v, __shfl_xor(v, 32));
     return v;
@@ -280,9 +329,11 @@ __device__ __forceinline__ void build_sample_table(const EtLayerDesc &d, const e
 // forward: fused epipolar sample + dot + masked softmax + weighted sum
 // ----------------------------------------------------------------------------
 // CPL: float4 channel groups per lane (C <= 256*CPL); KPL: samples per lane
-// (K <= 64*KPL); FAST: permlane/DPP reductions; CACHE: 2x2 tap register cache.
-template <int CPL, int KPL, bool FAST, bool CACHE>
-__global__ __launch_bounds__(kWave *kWavesPerBlock) void epipolar_fwd_kernel(const FwdParams p)
+// (K <= 64*KPL); BATCH: samples per cross-lane reduction; FAST: permlane/DPP
+// reductions; CACHE: 2x2 tap register cache; MINW: waves per SIMD the register
+// allocator must leave room for (__launch_bounds__ second argument).
+template <int CPL, int KPL, int BATCH, bool FAST, bool CACHE, int MINW>
+__global__ __launch_bounds__(kWave *kWavesPerBlock, MINW) void epipolar_fwd_kernel(const FwdParams p)
 {
     extern __shared__ float s_attn[];  // [K][kPixPerBlock]
     const EtLayerDesc &d = p.d;
@@ -309,7 +360,10 @@ __global__ __launch_bounds__(kWave *kWavesPerBlock) void epipolar_fwd_kernel(con
     for (int c = 0; c < CPL; ++c) voff[c] = min(lane + c * kWave, nvec - 1) * 16;
 
     for (int pp = 0; pp < kPixPerWave; ++pp) {
-        const int slot_in_block = wave * kPixPerWave + pp;
+        // consecutive pixels either per wave (0..3 | 4..7 | ..) or interleaved across the block's
+        // waves (wave w takes pixels w, w+4, ..), which keeps the four waves on neighbouring
+        // epipolar lines at the same time (shared rows hit in the CU's L1)
+        const int slot_in_block = p.interleave ? pp * kWavesPerBlock + wave : wave * kPixPerWave + pp;
         const int pix = pix_base + slot_in_block;
         if (pix >= HW) break;  // wave-uniform
         const int h = pix / W, w = pix - h * W;
@@ -338,11 +392,11 @@ __global__ __launch_bounds__(kWave *kWavesPerBlock) void epipolar_fwd_kernel(con
 #pragma unroll
         for (int s = 0; s < KPL; ++s) {
             const int kcount = min(kWave, K - s * kWave);  // samples held in this slot (uniform)
-            for (int kb = 0; kb < kcount; kb += kBatch) {
-                float4 S[kBatch][CPL];
-                float part[kBatch];
+            for (int kb = 0; kb < kcount; kb += BATCH) {
+                float4 S[BATCH][CPL];
+                float part[BATCH];
 #pragma unroll
-                for (int j = 0; j < kBatch; ++j) {
+                for (int j = 0; j < BATCH; ++j) {
                     const int kk = kb + j;
                     part[j] = 0.f;
 #pragma unroll
@@ -371,14 +425,13 @@ __global__ __launch_bounds__(kWave *kWavesPerBlock) void epipolar_fwd_kernel(con
                     }
                 }
                 // eight dot products -> 8-lane groups
-                const float u = reduce8<FAST>(part, lane);
-                const int jmine = ((lane >> 5) & 1) | (((lane >> 4) & 1) << 1) | (((lane >> 3) & 1) << 2);
-                const bool jvalid = (kb + jmine) < kcount;
+                const float u = reduce_batch<BATCH, FAST>(part, lane);
+                const bool jvalid = (kb + sample_of_lane<BATCH>(lane)) < kcount;
                 float sv = (u == 0.f) ? -1e10f : u;  // epipolar.py:298
                 float e;
                 if (d.softmax_enabled) {
                     sv = sv * d.softmax_scale;  // epipolar.py:306
-                    const float bm = group_max(jvalid ? sv : neg_inf);
+                    const float bm = group_max<BATCH>(jvalid ? sv : neg_inf);
                     const float m_new = fmaxf(m_run, bm);
                     const float alpha = expf(m_run - m_new);
                     e = jvalid ? expf(sv - m_new) : 0.f;
@@ -390,11 +443,11 @@ __global__ __launch_bounds__(kWave *kWavesPerBlock) void epipolar_fwd_kernel(con
                     e = jvalid ? sv : 0.f;
                 }
                 // keep the logit of sample (kb + j) in lane (kb + j) for the final pass
-                const float mine = __shfl(sv, lane_of_sample(lane & 7));
-                if ((lane >> 3) == (kb >> 3)) v_sim[s] = mine;
+                const float mine = __shfl(sv, lane_of_sample<BATCH>(lane & (BATCH - 1)));
+                if ((lane / BATCH) == (kb / BATCH)) v_sim[s] = mine;
 #pragma unroll
-                for (int j = 0; j < kBatch; ++j) {
-                    const float ej = lane_bcast(e, lane_of_sample(j));
+                for (int j = 0; j < BATCH; ++j) {
+                    const float ej = lane_bcast(e, lane_of_sample<BATCH>(j));
 #pragma unroll
                     for (int c = 0; c < CPL; ++c) acc[c] = f4_fma(ej, S[j][c], acc[c]);
                 }
@@ -565,10 +618,10 @@ __global__ __launch_bounds__(kWave *kWavesPerBlock) void epipolar_bwd_kernel(con
 #pragma unroll
         for (int s = 0; s < KPL; ++s) {
             const int kcount = min(kWave, K - s * kWave);
-            for (int kb = 0; kb < kcount; kb += kBatch) {
-                float p1[kBatch], p2[kBatch];
+            for (int kb = 0; kb < kcount; kb += 8) {
+                float p1[8], p2[8];
 #pragma unroll
-                for (int j = 0; j < kBatch; ++j) {
+                for (int j = 0; j < 8; ++j) {
                     const int kk = kb + j;
                     p1[j] = 0.f;
                     p2[j] = 0.f;
@@ -600,7 +653,7 @@ __global__ __launch_bounds__(kWave *kWavesPerBlock) void epipolar_bwd_kernel(con
                 const bool masked = (u1 == 0.f);
                 float sv = masked ? -1e10f : u1;
                 sv = d.softmax_enabled ? sv * d.softmax_scale : sv / (float)K;
-                const int srcl = lane_of_sample(lane & 7);
+                const int srcl = lane_of_sample<8>(lane & 7);
                 const float mine_l = __shfl(sv, srcl);
                 const float mine_d = __shfl(u2, srcl);
                 const int mine_m = __shfl((int)masked, srcl);
@@ -810,14 +863,25 @@ template <int CPL, int KPL>
 void launch_fwd(const FwdParams &p, int variant, dim3 grid, size_t lds, hipStream_t st)
 {
     const bool safe = variant & ET_VARIANT_SAFE_REDUCE, nocache = variant & ET_VARIANT_NO_TAP_CACHE;
-    if (!safe && !nocache)
-        hipLaunchKernelGGL((epipolar_fwd_kernel<CPL, KPL, true, true>), grid, dim3(256), lds, st, p);
-    else if (safe && !nocache)
-        hipLaunchKernelGGL((epipolar_fwd_kernel<CPL, KPL, false, true>), grid, dim3(256), lds, st, p);
-    else if (!safe && nocache)
-        hipLaunchKernelGGL((epipolar_fwd_kernel<CPL, KPL, true, false>), grid, dim3(256), lds, st, p);
-    else
-        hipLaunchKernelGGL((epipolar_fwd_kernel<CPL, KPL, false, false>), grid, dim3(256), lds, st, p);
+    const bool b4 = variant & ET_VARIANT_BATCH4;
+    const int occ = (variant & ET_VARIANT_OCC6) ? 6 : (variant & ET_VARIANT_OCC5) ? 5 : 1;
+#define ET_FWD(B, F, Cc, W) \
+    hipLaunchKernelGGL((epipolar_fwd_kernel<CPL, KPL, B, F, Cc, W>), grid, dim3(256), lds, st, p)
+    if (safe || nocache) {
+        // ablation / fallback variants, default register budget
+        if (safe && !nocache) { if (b4) ET_FWD(4, false, true, 1); else ET_FWD(8, false, true, 1); }
+        else if (!safe && nocache) ET_FWD(8, true, false, 1);
+        else ET_FWD(8, false, false, 1);
+    } else if (b4) {
+        if (occ == 6) ET_FWD(4, true, true, 6);
+        else if (occ == 5) ET_FWD(4, true, true, 5);
+        else ET_FWD(4, true, true, 1);
+    } else {
+        if (occ == 6) ET_FWD(8, true, true, 6);
+        else if (occ == 5) ET_FWD(8, true, true, 5);
+        else ET_FWD(8, true, true, 1);
+    }
+#undef ET_FWD
 }
 
 template <int CPD, int KPL>
@@ -869,6 +933,7 @@ int et_epipolar_forward(const EtLayerDesc *desc, const float *xs, const float *y
     const long long total = (long long)p.blocks_per_pair * desc->N;
     if (total > 0x7fffffffLL) return fail("grid too large");
     p.total_blocks = (int)total;
+    p.interleave = (desc->variant & ET_VARIANT_PIXEL_INTERLEAVE) ? 1 : 0;
     const dim3 grid((unsigned)total);
     const size_t lds = attn ? (size_t)desc->K * kPixPerBlock * sizeof(float) : 0;
     hipStream_t st = (hipStream_t)stream;

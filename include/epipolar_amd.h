@@ -64,6 +64,10 @@ typedef struct EtLayerDesc {
 /* Variant bits (EtLayerDesc.variant) */
 #define ET_VARIANT_SAFE_REDUCE 1  /* cross-lane sums via ds_bpermute only (no permlane swaps / DPP) */
 #define ET_VARIANT_NO_TAP_CACHE 2 /* reload all four taps for every sample                          */
+#define ET_VARIANT_PIXEL_INTERLEAVE 4 /* wave w of a block takes pixels w, w+4, .. instead of 4w..4w+3 */
+#define ET_VARIANT_BATCH4 8       /* cross-lane reductions per 4 samples (fewer registers) instead of 8 */
+#define ET_VARIANT_OCC5 16        /* compile for >= 5 waves per SIMD (<= 96 VGPRs)                       */
+#define ET_VARIANT_OCC6 32        /* compile for >= 6 waves per SIMD (<= 80 VGPRs, may spill)            */
 
 int et_abi_version(void);
 const char *et_last_error(void);

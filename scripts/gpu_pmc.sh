@@ -1,0 +1,39 @@
+#!/bin/bash
+# PMC counter passes for the fused forward kernel (one rocprofv3 run per counter
+# group; --pmc is never combined with sys/runtime tracing).  usage: gpu_pmc.sh TAG VARIANT [fwd|bwd]
+ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT="$ROOT/gpurun_out"; mkdir -p "$OUT"
+TAG=${1:-r01}; export PROF_VARIANT=${2:-0}; export PROF_KERNEL=${3:-fwd}
+cd /tmp && export TMPDIR=/tmp
+i=0
+for grp in \
+  "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA" \
+  "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_INSTS_SMEM SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VMEM" \
+  "GRBM_GUI_ACTIVE GRBM_COUNT" \
+  "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_EA0_RDREQ_sum" \
+  "FETCH_SIZE" \
+  "WRITE_SIZE" \
+  "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_TOTAL_ACCESSES_sum TCP_PENDING_STALL_CYCLES_sum" \
+  "TA_BUSY_avr TA_TA_BUSY_sum TCP_GATE_EN1_sum TCP_TA_DATA_STALL_CYCLES_sum" \
+  "VALUBusy SALUBusy MemUnitBusy MemUnitStalled" \
+  "OccupancyPercent L2CacheHit LDSBankConflict VALUUtilization"
+do
+  i=$((i+1))
+  timeout 300 rocprofv3 --pmc $grp --output-format csv -d "$OUT/pmc_${TAG}/g$i" -o pmc -- python "$ROOT/scripts/profile_kernel.py" > "$OUT/pmc_${TAG}_g$i.log" 2>&1
+  echo "group $i ($grp): exit $?"
+done
+python - <<PY
+import csv, glob, collections, os
+out = "$OUT/pmc_${TAG}"
+agg = collections.OrderedDict()
+for f in sorted(glob.glob(out + "/g*/**/*counter_collection.csv", recursive=True)):
+    for row in csv.DictReader(open(f)):
+        if "epipolar" not in row.get("Kernel_Name", ""):
+            continue
+        k = (row["Kernel_Name"].split("(")[0][-60:], row["Counter_Name"])
+        agg.setdefault(k, []).append(float(row["Counter_Value"]))
+with open(out + "_summary.txt", "w") as fh:
+    for (kn, cn), vals in agg.items():
+        line = "%-62s %-32s n=%d mean=%.6g" % (kn, cn, len(vals), sum(vals) / len(vals))
+        print(line); fh.write(line + "\n")
+PY

@@ -1,0 +1,28 @@
+#!/usr/bin/env python
+"""Launch the fused forward (default) or backward kernel a few times on the
+Config-2 workload -- the target of rocprofv3 --pmc passes (scripts/gpu_pmc.sh)."""
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from epipolar_transformers_amd import camera, ops, synthetic as syn  # noqa: E402
+
+variant = int(os.environ.get("PROF_VARIANT", 0))
+which = os.environ.get("PROF_KERNEL", "fwd")
+H, C, K = int(os.environ.get("PROF_HW", 64)), 256, int(os.environ.get("PROF_K", 64))
+dev = torch.device("cuda:0")
+P1, P2 = syn.make_pairs(32, 4, H * 4, seed=1000, jitter=(0.05, 8.0))
+g = torch.Generator(device=dev).manual_seed(0)
+ref = torch.randn(128, H, H, C, device=dev, generator=g).relu_()
+src = torch.randn(128, H, H, C, device=dev, generator=g).relu_()
+cam = camera.pair_algebra(P1, P2).to(dev)
+spec = ops.LayerSpec(H=H, W=H, K=K, variant=variant)
+for _ in range(int(os.environ.get("PROF_REPS", 3))):
+    if which == "fwd":
+        ops.forward_nhwc(spec, ref, src, cam)
+    else:
+        ops.backward_nhwc(spec, ref, src, cam, ref)
+torch.cuda.synchronize()

@@ -70,6 +70,8 @@ def test_camera_algebra_equals_reference_loop(oracle_mod, case):
     assert np.array_equal(cam[:, :12], a.reshape(-1, 12))
     assert np.array_equal(cam[:, 12:24], b.reshape(-1, 12))
     assert np.array_equal(cam[:, 24:], c)
+    # against the algebra frozen in the fixture (another CPU's LAPACK may differ in the last bits)
+    assert np.allclose(cam, d["cam"], rtol=1e-4, atol=1e-7)
 
 
 def _spec_from_golden(d, **kw):
@@ -84,7 +86,7 @@ def test_device_setup_code_reproduces_reference_sample_locs(lib, case):
     d = load_golden(case)
     spec = _spec_from_golden(d)
     m = d["dims"]
-    cam = camera.pair_algebra(torch.from_numpy(d["P1"]), torch.from_numpy(d["P2"])).numpy()
+    cam = d["cam"]
     desc = spec.desc(m["N"], m["C"])
     K, W = m["K"], m["W"]
     taps = np.zeros((K, 4), np.int32)

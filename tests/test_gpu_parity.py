@@ -41,7 +41,7 @@ def _dev(a):
 def _run_forward(env, d, variant=0):
     _lib, camera, ops = env
     spec = _spec(ops, d, variant=variant)
-    cam = camera.pair_algebra(torch.from_numpy(d["P1"]), torch.from_numpy(d["P2"])).cuda()
+    cam = _dev(d["cam"])
     ref = ops.to_nhwc(_dev(d["feat1"]))
     src = ops.to_nhwc(_dev(d["feat2"]))
     out, attn, corr = ops.forward_nhwc(spec, ref, src, cam)
@@ -59,7 +59,7 @@ def test_sample_locs_vs_reference(env, case):
     _lib, camera, ops = env
     d = load_golden(case)
     spec = _spec(ops, d)
-    cam = camera.pair_algebra(torch.from_numpy(d["P1"]), torch.from_numpy(d["P2"])).cuda()
+    cam = _dev(d["cam"])
     locs = ops.sample_locs(spec, cam).cpu().numpy()[:, :, d["rows"]]
     assert np.abs(locs - d["sample_locs"]).max() <= TOL_LOCS
     # the device evaluates the same IEEE float32 expression tree: expect bit equality
@@ -84,7 +84,7 @@ def test_forward_vs_oracle_full_tensors(env, oracle_mod, case):
     spec_o = oracle_mod.LayerSpec(m["H"], m["W"], m["K"], downsample=float(d["downsample"]),
                                   correct_normalize=m["correct"], softmax_scale=float(d["softmax_scale"]),
                                   softmax_enabled=m["softmax"])
-    want = oracle_mod.forward(spec_o, d["feat1"], d["feat2"], torch.from_numpy(d["P1"]), torch.from_numpy(d["P2"]))
+    want = oracle_mod.forward(spec_o, d["feat1"], d["feat2"], None, None, cam=d["cam"])
     _, _, _, _, out, attn, corr = _run_forward(env, d)
     _close(attn, want["attn"], TOL_ATTN)
     _close(out, want["out"], TOL_OUT)
@@ -144,6 +144,7 @@ def test_module_dropin_eval_and_train(env, case):
     from epipolar_transformers_amd import default_cfg
     from epipolar_transformers_amd.epipolar import Epipolar
 
+    _lib, camera, ops = env
     d = load_golden(case)
     m = d["dims"]
     cfg = default_cfg()
@@ -166,6 +167,20 @@ def test_module_dropin_eval_and_train(env, case):
         x, _, _, _ = mod.forward_fused(f1, f2, P1.cuda(), P2.cuda())   # device-resident P also accepted
     assert tuple(fin.shape) == d["finalout_eval"].shape and tuple(depth.shape) == (m["N"], m["K"], m["H"], m["W"])
     assert tuple(corr.shape) == (m["N"], m["H"], m["W"], 2) and tuple(locs.shape) == (m["N"], m["K"], m["H"], m["W"], 2)
+    if not np.array_equal(camera.pair_algebra(P1, P2).numpy(), d["cam"]):
+        # LAPACK on this host rounds the SVD differently from the machine that made the fixture: the
+        # module (which runs the algebra itself) can then only be held to the fixture away from the
+        # layer's discontinuities -- compare against the oracle fed with THIS host's algebra instead.
+        from oracle import oracle as orc
+
+        so = orc.LayerSpec(m["H"], m["W"], m["K"], downsample=float(d["downsample"]), correct_normalize=m["correct"],
+                           softmax_scale=float(d["softmax_scale"]), softmax_enabled=m["softmax"])
+        w = orc.forward(so, d["feat1"], d["feat2"], P1, P2)
+        for key, tr in (("finalout_eval", False), ("finalout_train", True)):
+            d[key] = orc.epilogue(w["out"], d["feat1"], d["z_weight"], d["z_bias"], d["bn_weight"], d["bn_bias"],
+                                  d["bn_running_mean"], d["bn_running_var"], training=tr)[0].numpy()
+        d["sample_locs"] = w["sample_locs"][:, :, d["rows"]]
+        d["grad_feat1"], d["grad_feat2"] = orc.backward(so, d["feat1"], d["feat2"], w["sample_locs"], d["grad_out"])
     _close(fin.cpu().numpy(), d["finalout_eval"], TOL_OUT)
     _close(x.cpu().numpy(), d["finalout_eval"] + d["feat1"], TOL_OUT)     # resnet.py:388
     assert np.array_equal(locs.cpu().numpy().transpose(1, 0, 2, 3, 4)[:, :, d["rows"]], d["sample_locs"])

@@ -22,7 +22,7 @@ def _spec(orc, d):
 def test_sample_locs_bit_exact(oracle_mod, case):
     d = load_golden(case)
     spec = _spec(oracle_mod, d)
-    locs = oracle_mod.sample_locs(spec, torch.from_numpy(d["P1"]), torch.from_numpy(d["P2"]))
+    locs = oracle_mod.sample_locs(spec, None, None, cam=d["cam"])
     got = locs[:, :, d["rows"]]
     assert got.shape == d["sample_locs"].shape
     assert np.array_equal(got, d["sample_locs"]), "max|d|=%g" % np.abs(got - d["sample_locs"]).max()
@@ -32,7 +32,7 @@ def test_sample_locs_bit_exact(oracle_mod, case):
 def test_forward_matches_reference(oracle_mod, case):
     d = load_golden(case)
     spec = _spec(oracle_mod, d)
-    r = oracle_mod.forward(spec, d["feat1"], d["feat2"], torch.from_numpy(d["P1"]), torch.from_numpy(d["P2"]))
+    r = oracle_mod.forward(spec, d["feat1"], d["feat2"], None, None, cam=d["cam"])
     attn = r["attn"][:, :, d["rows"]]
     # relative term only matters for the softmax-off case, where a masked
     # sample keeps its -1e10/K logit as a weight (epipolar.py:298,311)
@@ -52,7 +52,7 @@ def test_zero_feature_pixel_gives_uniform_attention(oracle_mod, case):
     if not (d["feat1"][0, :, 3, 5] == 0).all() or not d["dims"]["softmax"]:
         pytest.skip("case has no all-zero reference pixel")
     spec = _spec(oracle_mod, d)
-    r = oracle_mod.forward(spec, d["feat1"], d["feat2"], torch.from_numpy(d["P1"]), torch.from_numpy(d["P2"]))
+    r = oracle_mod.forward(spec, d["feat1"], d["feat2"], None, None, cam=d["cam"])
     K = d["dims"]["K"]
     assert np.allclose(r["attn"][0, :, 3, 5], 1.0 / K, atol=1e-7)       # epipolar.py:298 (H3)
 
@@ -72,7 +72,7 @@ def test_epilogue_matches_reference(oracle_mod, case):
 def test_backward_matches_reference_autograd(oracle_mod, case):
     d = load_golden(case)
     spec = _spec(oracle_mod, d)
-    locs = oracle_mod.sample_locs(spec, torch.from_numpy(d["P1"]), torch.from_numpy(d["P2"]))
+    locs = oracle_mod.sample_locs(spec, None, None, cam=d["cam"])
     g1, g2 = oracle_mod.backward(spec, d["feat1"], d["feat2"], locs, d["grad_out"])
     for got, want in ((g1, d["grad_feat1"]), (g2, d["grad_feat2"])):
         scale = np.abs(want).max()
