@@ -6,8 +6,9 @@ SVD, a 3x3 inverse and the epipole in float32 (modeling/layers/epipolar.py:336,
 sample locations by up to 4e-3, so parity with the
 reference's CPU path requires *these exact* float32 values; every per-pixel step
 after them runs on the GPU.  This module produces them batched -- bit-identical
-to the reference's per-matrix loop at ~0.4 ms for 128 pairs instead of ~4 ms --
-and packs them in the `cam` layout of include/epipolar_amd.h (ET_CAM_STRIDE).
+to the reference's per-matrix loop ON THE HOST IT RUNS ON (the last bits depend on
+the host's BLAS kernel selection, see `_calibrate`) at ~0.4 ms for 128 pairs
+instead of 2-4 ms -- and packs them in the `cam` layout of include/epipolar_amd.h.
 """
 from __future__ import annotations
 
@@ -16,23 +17,73 @@ import torch
 ET_CAM_STRIDE = 27
 
 
-def batched_pinverse(P: torch.Tensor) -> torch.Tensor:
-    """`torch.stack([p.pinverse() for p in P])` (epipolar.py:336), batched.
+def _pinverse_loop(P: torch.Tensor) -> torch.Tensor:
+    """The reference's own formulation (epipolar.py:336)."""
+    return torch.stack([p.pinverse() for p in P])
 
-    torch.pinverse(A) is (Vh^T * 1/S) @ U^T from the LAPACK SVD.  The batched
-    SVD is bit-identical to the per-matrix one; the tiny product is not when
-    done by bmm (no FMA) instead of mm (BLAS, ascending-k FMA chain), so the
-    FMA chain is spelled out here through float64 (exact products).
-    """
+
+def _svd_factors(P):
+    # torch.pinverse(A) is (Vh^T * 1/S) @ U^T from the LAPACK SVD (rcond 1e-15); the batched SVD
+    # is bit-identical to the per-matrix one, only the tiny 4x3 @ 3x3 product is not necessarily
     U, S, Vh = torch.linalg.svd(P, full_matrices=False)
-    cutoff = 1e-15 * S.amax(-1, keepdim=True)          # pinverse's default rcond
+    cutoff = 1e-15 * S.amax(-1, keepdim=True)
     s_inv = torch.where(S > cutoff, 1.0 / S, torch.zeros_like(S))
-    A = (Vh.transpose(-1, -2) * s_inv.unsqueeze(-2)).double()      # (N,4,3)
-    B = U.transpose(-1, -2).double()                               # (N,3,3)
+    return Vh.transpose(-1, -2) * s_inv.unsqueeze(-2), U.transpose(-1, -2)      # (N,4,3), (N,3,3)
+
+
+def _pinv_fma_chain(P):
+    """mm as an ascending-k FMA chain (what MKL runs on Intel hosts), spelled through float64."""
+    A, B = _svd_factors(P)
+    A, B = A.double(), B.double()
     acc = (A[..., :, 0:1] * B[..., 0:1, :]).float()
     acc = (A[..., :, 1:2] * B[..., 1:2, :] + acc.double()).float()
     acc = (A[..., :, 2:3] * B[..., 2:3, :] + acc.double()).float()
     return acc
+
+
+def _pinv_mul_add(P):
+    """mm as separately rounded products and sums (what MKL runs on the EPYC hosts of the GPU boxes)."""
+    A, B = _svd_factors(P)
+    return ((A[..., :, 0:1] * B[..., 0:1, :]) + (A[..., :, 1:2] * B[..., 1:2, :])) + (A[..., :, 2:3] * B[..., 2:3, :])
+
+
+_BATCHED_CANDIDATES = (("linalg.pinv", torch.linalg.pinv), ("mul_add", _pinv_mul_add), ("fma_chain", _pinv_fma_chain))
+_calibrated = None          # name of the batched formulation that reproduces the loop on this host, or "loop"
+
+
+def _calibrate():
+    """The last bits of the reference's pinverse depend on which kernel the host's BLAS picks for a
+    4x3 @ 3x3 product, and the layer is discontinuous in them.  Find, once per
+    process, a batched formulation that is bit-identical to the reference loop on THIS host."""
+    global _calibrated
+    g = torch.Generator().manual_seed(1234)
+    probe = torch.randn(24, 3, 4, generator=g) * torch.tensor([300.0, 300.0, 300.0, 1.0e6])
+    probe[:, 2] = torch.randn(24, 4, generator=g) * torch.tensor([1.0, 1.0, 1.0, 5.0e3])
+    want = _pinverse_loop(probe)
+    _calibrated = "loop"
+    for name, fn in _BATCHED_CANDIDATES:
+        try:
+            if torch.equal(fn(probe), want):
+                _calibrated = name
+                break
+        except Exception:      # pragma: no cover - a candidate the installed torch cannot run
+            continue
+    return _calibrated
+
+
+def batched_pinverse(P: torch.Tensor) -> torch.Tensor:
+    """`torch.stack([p.pinverse() for p in P])` (epipolar.py:336) at batched cost (~0.4 ms instead of
+    ~4 ms for 128 pairs), bit-identical to that loop on the host it runs on: calibrated once, and
+    spot-checked against the loop on two matrices of every call (falls back to the loop on mismatch)."""
+    n = P.shape[0]
+    method = _calibrated or _calibrate()
+    if method == "loop" or n <= 4:
+        return _pinverse_loop(P)
+    out = dict(_BATCHED_CANDIDATES)[method](P)
+    for i in (0, n - 1):
+        if not torch.equal(out[i], P[i].pinverse()):
+            return _pinverse_loop(P)
+    return out
 
 
 def pair_algebra(P_ref: torch.Tensor, P_src: torch.Tensor) -> torch.Tensor:

@@ -269,6 +269,16 @@ __device__ __forceinline__ float4 f4_mul(float s, const float4 &a)
     return make_float4(s * a.x, s * a.y, s * a.z, s * a.w);
 }
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// a . b through packed fp32: (a.xy * b.xy), fma with (a.zw, b.zw), one add
+__device__ __forceinline__ float f4_dot(const float4 &a, const float4 &b)
+{
+    const f32x2 lo = f32x2{a.x, a.y} * f32x2{b.x, b.y};
+    const f32x2 t = __builtin_elementwise_fma(f32x2{a.z, a.w}, f32x2{b.z, b.w}, lo);
+    return t.x + t.y;
+}
+
 __device__ __forceinline__ float f4_dot_acc(const float4 &a, const float4 &b, float acc)
 {
     acc = fmaf(a.x, b.x, acc);
@@ -331,11 +341,14 @@ __device__ __forceinline__ void build_sample_table(const EtLayerDesc &d, const e
 // CPL: float4 channel groups per lane (C <= 256*CPL); KPL: samples per lane
 // (K <= 64*KPL); BATCH: samples per cross-lane reduction; FAST: permlane/DPP
 // reductions; CACHE: 2x2 tap register cache; MINW: waves per SIMD the register
-// allocator must leave room for (__launch_bounds__ second argument).
-template <int CPL, int KPL, int BATCH, bool FAST, bool CACHE, int MINW>
+// allocator must leave room for (__launch_bounds__ second argument); RAGGED: K is
+// not a multiple of BATCH, so batches carry per-sample validity logic.
+template <int CPL, int KPL, int BATCH, bool FAST, bool CACHE, int MINW, bool RAGGED>
 __global__ __launch_bounds__(kWave *kWavesPerBlock, MINW) void epipolar_fwd_kernel(const FwdParams p)
 {
-    extern __shared__ float s_attn[];  // [K][kPixPerBlock]
+    // dynamic LDS: [K][16] attention tile (only when attn is requested), then one
+    // [KPL*64] float4 table of bilinear weights per wave
+    extern __shared__ float s_dyn[];
     const EtLayerDesc &d = p.d;
     const int H = d.H, W = d.W, C = d.C, K = d.K;
     const int HW = H * W;
@@ -347,6 +360,8 @@ __global__ __launch_bounds__(kWave *kWavesPerBlock, MINW) void epipolar_fwd_kern
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int pix_base = pb * kPixPerBlock;
+    float *s_attn = s_dyn;
+    float4 *s_wt = reinterpret_cast<float4 *>(s_dyn + (p.attn ? K * kPixPerBlock : 0)) + wave * (KPL * kWave);
 
     const float *cam = p.cam + (size_t)n * ET_CAM_STRIDE;
     const __amdgpu_buffer_rsrc_t src = make_rsrc(p.fsrc + (size_t)n * HW * C, (unsigned)HW * C * 4u);
@@ -374,7 +389,13 @@ __global__ __launch_bounds__(kWave *kWavesPerBlock, MINW) void epipolar_fwd_kern
         build_sample_table<KPL, CACHE>(d, seg, p.steps, lane, row_bytes, tb);
         float v_sim[KPL];
 #pragma unroll
-        for (int s = 0; s < KPL; ++s) v_sim[s] = neg_inf;
+        for (int s = 0; s < KPL; ++s) {
+            v_sim[s] = neg_inf;
+            // a sample's four weights come back as ONE broadcast ds_read_b128 (same address in
+            // every lane) instead of four v_readlane
+            s_wt[s * kWave + lane] = make_float4(tb.w[s][0], tb.w[s][1], tb.w[s][2], tb.w[s][3]);
+        }
+        __builtin_amdgcn_wave_barrier();
 
         // ---- lanes <-> channels -------------------------------------------
         float4 f1[CPL], acc[CPL], R[4][CPL];
@@ -399,8 +420,12 @@ __global__ __launch_bounds__(kWave *kWavesPerBlock, MINW) void epipolar_fwd_kern
                 for (int j = 0; j < BATCH; ++j) {
                     const int kk = kb + j;
                     part[j] = 0.f;
+                    if (RAGGED) {
 #pragma unroll
-                    for (int c = 0; c < CPL; ++c) S[j][c] = f4_zero();
+                        for (int c = 0; c < CPL; ++c) S[j][c] = f4_zero();
+                    }
+                    // (the branch is kept even when it is always taken: per-sample basic blocks stop the
+                    //  compiler from renaming the tap registers across samples, which costs ~100 VGPRs)
                     if (kk < kcount) {  // wave-uniform
                         const int need = __builtin_amdgcn_readlane(tb.need[s], kk);
 #pragma unroll
@@ -411,8 +436,8 @@ __global__ __launch_bounds__(kWave *kWavesPerBlock, MINW) void epipolar_fwd_kern
                                 for (int c = 0; c < CPL; ++c) R[r][c] = buf_load_f4(src, voff[c], off);
                             }
                         }
-                        const float w0 = lane_bcast(tb.w[s][0], kk), w1 = lane_bcast(tb.w[s][1], kk);
-                        const float w2 = lane_bcast(tb.w[s][2], kk), w3 = lane_bcast(tb.w[s][3], kk);
+                        const float4 wv = s_wt[s * kWave + kk];
+                        const float w0 = wv.x, w1 = wv.y, w2 = wv.z, w3 = wv.w;
 #pragma unroll
                         for (int c = 0; c < CPL; ++c) {
                             float4 sv = f4_mul(w0, R[0][c]);
@@ -420,21 +445,23 @@ __global__ __launch_bounds__(kWave *kWavesPerBlock, MINW) void epipolar_fwd_kern
                             sv = f4_fma(w2, R[2][c], sv);
                             sv = f4_fma(w3, R[3][c], sv);
                             S[j][c] = sv;
-                            part[j] = f4_dot_acc(sv, f1[c], part[j]);
+                            part[j] += f4_dot(sv, f1[c]);
                         }
                     }
                 }
                 // eight dot products -> 8-lane groups
                 const float u = reduce_batch<BATCH, FAST>(part, lane);
-                const bool jvalid = (kb + sample_of_lane<BATCH>(lane)) < kcount;
+                const bool jvalid = !RAGGED || (kb + sample_of_lane<BATCH>(lane)) < kcount;
                 float sv = (u == 0.f) ? -1e10f : u;  // epipolar.py:298
                 float e;
                 if (d.softmax_enabled) {
                     sv = sv * d.softmax_scale;  // epipolar.py:306
                     const float bm = group_max<BATCH>(jvalid ? sv : neg_inf);
                     const float m_new = fmaxf(m_run, bm);
-                    const float alpha = expf(m_run - m_new);
-                    e = jvalid ? expf(sv - m_new) : 0.f;
+                    // accumulator weights only need ~1e-6 relative accuracy (the returned attention is
+                    // recomputed with expf in the final pass): hardware exp2
+                    const float alpha = __expf(m_run - m_new);
+                    e = jvalid ? __expf(sv - m_new) : 0.f;
 #pragma unroll
                     for (int c = 0; c < CPL; ++c) acc[c] = f4_mul(alpha, acc[c]);
                     m_run = m_new;
@@ -865,8 +892,14 @@ void launch_fwd(const FwdParams &p, int variant, dim3 grid, size_t lds, hipStrea
     const bool safe = variant & ET_VARIANT_SAFE_REDUCE, nocache = variant & ET_VARIANT_NO_TAP_CACHE;
     const bool b4 = variant & ET_VARIANT_BATCH4;
     const int occ = (variant & ET_VARIANT_OCC6) ? 6 : (variant & ET_VARIANT_OCC5) ? 5 : 1;
-#define ET_FWD(B, F, Cc, W) \
-    hipLaunchKernelGGL((epipolar_fwd_kernel<CPL, KPL, B, F, Cc, W>), grid, dim3(256), lds, st, p)
+    const bool ragged = (p.d.K % 8) != 0;   // K % 4 == 0 but % 8 != 0 also takes the ragged build (fewer variants)
+#define ET_FWD(B, F, Cc, W)                                                                                  \
+    do {                                                                                                     \
+        if (ragged)                                                                                          \
+            hipLaunchKernelGGL((epipolar_fwd_kernel<CPL, KPL, B, F, Cc, W, true>), grid, dim3(256), lds, st, p);  \
+        else                                                                                                 \
+            hipLaunchKernelGGL((epipolar_fwd_kernel<CPL, KPL, B, F, Cc, W, false>), grid, dim3(256), lds, st, p); \
+    } while (0)
     if (safe || nocache) {
         // ablation / fallback variants, default register budget
         if (safe && !nocache) { if (b4) ET_FWD(4, false, true, 1); else ET_FWD(8, false, true, 1); }
@@ -935,7 +968,9 @@ int et_epipolar_forward(const EtLayerDesc *desc, const float *xs, const float *y
     p.total_blocks = (int)total;
     p.interleave = (desc->variant & ET_VARIANT_PIXEL_INTERLEAVE) ? 1 : 0;
     const dim3 grid((unsigned)total);
-    const size_t lds = attn ? (size_t)desc->K * kPixPerBlock * sizeof(float) : 0;
+    const int kpl_ = (desc->K + 63) / 64;
+    const size_t lds = (attn ? (size_t)desc->K * kPixPerBlock * sizeof(float) : 0) +
+                       (size_t)kWavesPerBlock * kpl_ * kWave * 4 * sizeof(float);
     hipStream_t st = (hipStream_t)stream;
     const int cpl = (desc->C + 255) / 256, kpl = (desc->K + 63) / 64;
     const int v = desc->variant;
