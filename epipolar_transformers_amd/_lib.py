@@ -15,6 +15,13 @@ LIB_PATH = os.path.join(_PKG, "lib", "libepipolar_amd.so")
 ET_CAM_STRIDE = 27
 ET_VARIANT_SAFE_REDUCE = 1
 ET_VARIANT_NO_TAP_CACHE = 2
+ET_VARIANT_PIXEL_INTERLEAVE = 4
+ET_VARIANT_BATCH4 = 8
+ET_VARIANT_OCC5 = 16
+ET_VARIANT_OCC6 = 32
+ET_VARIANT_ABLATE_NO_LOADS = 64
+ET_VARIANT_ABLATE_ONE_ROW = 128
+ET_VARIANT_BASELINE = 256
 ET_ABI_VERSION = 1
 
 

@@ -66,6 +66,7 @@ struct FwdParams {
     int blocks_per_pair;
     int total_blocks;
     int interleave;
+    int ablate;  // profiling only: 1 = issue no tap loads after the first sample, 2 = every tap reads row 0
 };
 
 struct BwdParams {
@@ -387,6 +388,16 @@ __global__ __launch_bounds__(kWave *kWavesPerBlock, MINW) void epipolar_fwd_kern
         const et::Segment seg = et::epipolar_segment(d, cam, p.xs[w], p.ys[h]);
         SampleTable<KPL> tb;
         build_sample_table<KPL, CACHE>(d, seg, p.steps, lane, row_bytes, tb);
+        if (p.ablate) {  // roofline ablations (results are wrong by construction)
+#pragma unroll
+            for (int s = 0; s < KPL; ++s) {
+                if (p.ablate == 1 && (s > 0 || lane > 0)) tb.need[s] = 0;
+                if (p.ablate == 2) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) tb.off[s][r] = 0;
+                }
+            }
+        }
         float v_sim[KPL];
 #pragma unroll
         for (int s = 0; s < KPL; ++s) {
@@ -967,13 +978,20 @@ int et_epipolar_forward(const EtLayerDesc *desc, const float *xs, const float *y
     if (total > 0x7fffffffLL) return fail("grid too large");
     p.total_blocks = (int)total;
     p.interleave = (desc->variant & ET_VARIANT_PIXEL_INTERLEAVE) ? 1 : 0;
+    p.ablate = (desc->variant & ET_VARIANT_ABLATE_NO_LOADS) ? 1 : (desc->variant & ET_VARIANT_ABLATE_ONE_ROW) ? 2 : 0;
     const dim3 grid((unsigned)total);
     const int kpl_ = (desc->K + 63) / 64;
     const size_t lds = (attn ? (size_t)desc->K * kPixPerBlock * sizeof(float) : 0) +
                        (size_t)kWavesPerBlock * kpl_ * kWave * 4 * sizeof(float);
     hipStream_t st = (hipStream_t)stream;
     const int cpl = (desc->C + 255) / 256, kpl = (desc->K + 63) / 64;
-    const int v = desc->variant;
+    // variant 0 = the tuned default (measured on MI355X, profiles/): batches of 4 samples,
+    // <= 96 VGPRs (5 waves/SIMD), waves of a block interleaved over neighbouring pixels
+    int v = desc->variant;
+    if ((v & ~(ET_VARIANT_ABLATE_NO_LOADS | ET_VARIANT_ABLATE_ONE_ROW)) == 0)
+        v |= ET_VARIANT_BATCH4 | ET_VARIANT_OCC5 | ET_VARIANT_PIXEL_INTERLEAVE;
+    if (v & ET_VARIANT_BASELINE) v &= ~(ET_VARIANT_BATCH4 | ET_VARIANT_OCC5 | ET_VARIANT_OCC6 | ET_VARIANT_PIXEL_INTERLEAVE);
+    p.interleave = (v & ET_VARIANT_PIXEL_INTERLEAVE) ? 1 : 0;
     if (cpl == 1) {
         if (kpl == 1) launch_fwd<1, 1>(p, v, grid, lds, st);
         else if (kpl == 2) launch_fwd<1, 2>(p, v, grid, lds, st);
