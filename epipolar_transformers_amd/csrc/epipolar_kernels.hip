@@ -430,8 +430,8 @@ __global__ __launch_bounds__(kWave *kWavesPerBlock, MINW) void epipolar_fwd_kern
 #pragma unroll
                 for (int j = 0; j < BATCH; ++j) {
                     const int kk = kb + j;
-                    part[j] = 0.f;
                     if (RAGGED) {
+                        part[j] = 0.f;
 #pragma unroll
                         for (int c = 0; c < CPL; ++c) S[j][c] = f4_zero();
                     }
@@ -456,7 +456,7 @@ __global__ __launch_bounds__(kWave *kWavesPerBlock, MINW) void epipolar_fwd_kern
                             sv = f4_fma(w2, R[2][c], sv);
                             sv = f4_fma(w3, R[3][c], sv);
                             S[j][c] = sv;
-                            part[j] += f4_dot(sv, f1[c]);
+                            part[j] = (c == 0) ? f4_dot(sv, f1[c]) : part[j] + f4_dot(sv, f1[c]);
                         }
                     }
                 }

@@ -1,0 +1,55 @@
+#!/usr/bin/env python
+"""Launcher with the reference's CLI (`main.py -c/--cfg FILE [KEY VALUE ...]`,
+reference main.py:21-45) that runs the REFERENCE training/eval program with the
+MI355X-native epipolar layer swapped in.  Nothing in the reference tree is
+edited: it is put on sys.path (REFERENCE_ROOT env, default /root/reference),
+a yacs stand-in is installed if yacs is missing, and the name `Epipolar` that
+the reference pose backbone looks up when it is constructed
+(modeling/backbones/resnet.py:299-305) is rebound to ours.  Every reference
+YAML therefore runs unchanged.  See INTEGRATION.md.
+"""
+import os
+import sys
+import types
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+REFERENCE_ROOT = os.environ.get("REFERENCE_ROOT", "/root/reference")
+
+
+def install(reference_root=REFERENCE_ROOT):
+    """Make the reference importable and swap the operator in.  Returns the reference `cfg`."""
+    if ROOT not in sys.path:
+        sys.path.insert(0, ROOT)
+    from epipolar_transformers_amd import config as amd_config
+
+    try:
+        import yacs.config  # noqa: F401
+    except ImportError:
+        yacs = types.ModuleType("yacs")
+        yacs.config = types.ModuleType("yacs.config")
+        yacs.config.CfgNode = amd_config.CfgNode
+        sys.modules["yacs"], sys.modules["yacs.config"] = yacs, yacs.config
+    if reference_root not in sys.path:
+        sys.path.insert(0, reference_root)
+    from core import cfg as ref_cfg                      # reference core/config.py singleton
+
+    amd_config.use_cfg(ref_cfg)                          # our layer reads the SAME global cfg the reference does
+    # the reference opens a log file under cfg.FOLDER_NAME while importing its backbone module
+    os.makedirs(os.path.normpath(str(ref_cfg.FOLDER_NAME)), exist_ok=True)
+    from epipolar_transformers_amd.epipolar import Epipolar
+    import modeling.backbones.resnet as ref_resnet       # reference module; its PoseResNet builds `Epipolar()`
+
+    ref_resnet.Epipolar = Epipolar
+    return ref_cfg
+
+
+def main():
+    install()
+    import runpy
+
+    sys.argv[0] = os.path.join(REFERENCE_ROOT, "main.py")
+    runpy.run_path(sys.argv[0], run_name="__main__")
+
+
+if __name__ == "__main__":
+    main()

@@ -188,8 +188,10 @@ def test_module_dropin_eval_and_train(env, case):
     with torch.no_grad():
         fin_t, _, _, _ = mod(f1, f2, P1, P2)
     _close(fin_t.cpu().numpy(), d["finalout_train"], TOL_OUT, rtol=1e-5)
-    _close(mod.bn.running_mean.cpu().numpy(), d["bn_running_mean_after"], 1e-5, rtol=1e-5)
-    _close(mod.bn.running_var.cpu().numpy(), d["bn_running_var_after"], 1e-5, rtol=1e-5)
+    # batch statistics are sums over N*H*W values; with the soft-max off a masked sample keeps its
+    # -1e10/K weight, the sums cancel by ~3 orders of magnitude and carry that much float32 noise
+    _close(mod.bn.running_mean.cpu().numpy(), d["bn_running_mean_after"], 1e-5, rtol=1e-5 if m["softmax"] else 2e-3)
+    _close(mod.bn.running_var.cpu().numpy(), d["bn_running_var_after"], 1e-5, rtol=1e-5 if m["softmax"] else 2e-3)
     # autograd through the module (train mode), gradients of sum(out * grad_out) w.r.t. both maps
     a1, a2 = f1.clone().requires_grad_(True), f2.clone().requires_grad_(True)
     out, _, _ = mod.attend(a1, a2, P1, P2)
@@ -287,3 +289,45 @@ def test_config2_full_batch_properties(env):
     sub = slice(40, 44)
     out_p, attn_p, _ = ops.forward_nhwc(spec, ref[sub].contiguous(), src[sub].contiguous(), cam[sub].contiguous())
     assert torch.equal(out_p, out[sub]) and torch.equal(attn_p, attn[sub])
+
+
+def test_pose_backbone_multiview_forward(env, oracle_mod):
+    """Row (b) of the boundary on the GPU: `epipolarposeR-18` called the way Modelbuilder does
+    (model.py:241-247): a source pass with other_inputs=None, then the reference pass with the
+    source features; the fused layer inside must equal trunk features -> oracle -> epilogue."""
+    _lib, camera, ops = env
+    from epipolar_transformers_amd import backbones, default_cfg, synthetic as syn
+
+    size, hs = 64, 16
+    cfg = default_cfg()
+    cfg.merge_from_list(["BACKBONE.BODY", "epipolarposeR-18", "BACKBONE.PRETRAINED", False,
+                         "KEYPOINT.HEATMAP_SIZE", (hs, hs), "KEYPOINT.NUM_PTS", 17, "KEYPOINT.SIGMA", 2.0,
+                         "DATASETS.IMAGE_SIZE", (size, size), "EPIPOLAR.MERGE", "late", "EPIPOLAR.ATTENTION", "avg",
+                         "EPIPOLAR.PARAMETERIZED", ("z",), "EPIPOLAR.ZRESIDUAL", True,
+                         "EPIPOLAR.USE_CORRECT_NORMALIZE", True, "EPIPOLAR.SAMPLESIZE", 16])
+    torch.manual_seed(3)
+    net = backbones.build_backbone(cfg).cuda().eval()
+    with torch.no_grad():
+        net.epipolar_sampler.bn.weight.normal_(1, 0.1)
+        net.epipolar_sampler.bn.bias.normal_(0, 0.1)
+    P1, P2 = syn.make_pairs(1, 4, size, seed=2, jitter=(0.03, 2.0))
+    img = torch.randn(4, 3, size, size, device="cuda")
+    other = img.roll(-1, 0)                                        # view v+1 is the source of view v
+    with torch.no_grad():
+        src_feat = net(other)[0]                                   # model.py:244
+        feat, heat, locs, scos, corr, depth, sl, _ = net(img, [src_feat, P2, None, P1, None, None, other])
+    assert tuple(heat[0].shape) == (4, 17, hs, hs) and tuple(depth.shape) == (4, 16, hs, hs)
+    f1, f2 = feat.float().cpu(), src_feat.float().cpu()
+    so = oracle_mod.LayerSpec(hs, hs, 16)
+    cam = camera.pair_algebra(P1, P2).numpy()
+    want = oracle_mod.forward(so, f1.numpy(), f2.numpy(), None, None, cam=cam)
+    s = net.epipolar_sampler
+    fin, fused = oracle_mod.epilogue(want["out"], f1.numpy(), s.z.weight.detach().cpu().numpy(),
+                                     s.z.bias.detach().cpu().numpy(), s.bn.weight.detach().cpu().numpy(),
+                                     s.bn.bias.detach().cpu().numpy(), s.bn.running_mean.cpu().numpy(),
+                                     s.bn.running_var.cpu().numpy(), training=False)
+    with torch.no_grad():
+        want_heat = net.final_layer(fused.cuda()).cpu().numpy()
+    scale = max(1.0, float(np.abs(want_heat).max()))
+    assert np.abs(heat[0].cpu().numpy() - want_heat).max() <= 1e-4 * scale
+    _close(depth.cpu().numpy(), want["attn"], TOL_ATTN)
