@@ -22,7 +22,7 @@ ET_VARIANT_OCC6 = 32
 ET_VARIANT_ABLATE_NO_LOADS = 64
 ET_VARIANT_ABLATE_ONE_ROW = 128
 ET_VARIANT_BASELINE = 256
-ET_ABI_VERSION = 1
+ET_ABI_VERSION = 2
 
 
 class EpipolarAmdError(RuntimeError):
@@ -50,7 +50,7 @@ _SIGNATURES = {
     "et_abi_version": (ctypes.c_int, []),
     "et_last_error": (ctypes.c_char_p, []),
     "et_sample_locs": (ctypes.c_int, [_D, _P, _P, _P, _P, _P, _P]),
-    "et_epipolar_forward": (ctypes.c_int, [_D, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "et_epipolar_forward": (ctypes.c_int, [_D, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "et_epipolar_backward": (ctypes.c_int, [_D, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "et_residual_epilogue": (ctypes.c_int, [ctypes.c_int64, ctypes.c_int32, _P, _P, _P, _P, _P, _P, _P, _P]),
     "et_nchw_to_nhwc": (ctypes.c_int, [ctypes.c_int32] * 4 + [_P, _P, _P]),

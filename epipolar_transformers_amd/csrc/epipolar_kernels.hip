@@ -63,6 +63,8 @@ struct FwdParams {
     const float *xs, *ys, *steps, *cam;
     const float *fref, *fsrc;
     float *out, *attn, *corr;
+    const float *res_bias;
+    float *res_base;
     int blocks_per_pair;
     int total_blocks;
     int interleave;
@@ -418,6 +420,23 @@ __global__ __launch_bounds__(kWave *kWavesPerBlock, MINW) void epipolar_fwd_kern
             acc[c] = f4_zero();
 #pragma unroll
             for (int r = 0; r < 4; ++r) R[r][c] = f4_zero();
+        }
+        if (p.res_base) {
+            // additive term of the residual fusion, while the reference row is still in registers
+            float4 *b4 = reinterpret_cast<float4 *>(p.res_base + ((size_t)n * HW + pix) * C);
+            const float4 *bias4 = reinterpret_cast<const float4 *>(p.res_bias);
+#pragma unroll
+            for (int c = 0; c < CPL; ++c) {
+                const int v = lane + c * kWave;
+                if (v < nvec) {
+                    float4 r = f1[c];
+                    if (bias4) {
+                        const float4 bb = bias4[v];
+                        r = make_float4(r.x + bb.x, r.y + bb.y, r.z + bb.z, r.w + bb.w);
+                    }
+                    b4[v] = r;
+                }
+            }
         }
         float m_run = neg_inf;
 
@@ -962,16 +981,18 @@ int et_sample_locs(const EtLayerDesc *desc, const float *xs, const float *ys, co
 
 int et_epipolar_forward(const EtLayerDesc *desc, const float *xs, const float *ys, const float *steps,
                         const float *cam, const float *feat_ref, const float *feat_src, float *out,
-                        float *attn, float *corr_pos, void *stream)
+                        float *attn, float *corr_pos, const float *res_bias, float *res_base, void *stream)
 {
     if (int e = validate(desc)) return e;
     if (!xs || !ys || !steps || !cam || !feat_ref || !feat_src || !out)
         return fail("et_epipolar_forward: NULL pointer");
+    if (res_bias && !res_base) return fail("et_epipolar_forward: res_bias given without res_base");
     FwdParams p;
     p.d = *desc;
     p.xs = xs; p.ys = ys; p.steps = steps; p.cam = cam;
     p.fref = feat_ref; p.fsrc = feat_src;
     p.out = out; p.attn = attn; p.corr = corr_pos;
+    p.res_bias = res_bias; p.res_base = res_base;
     const int HW = desc->H * desc->W;
     p.blocks_per_pair = (HW + kPixPerBlock - 1) / kPixPerBlock;
     const long long total = (long long)p.blocks_per_pair * desc->N;

@@ -101,35 +101,35 @@ class Epipolar(nn.Module):
         cam = self._cams.get(P1, P2, feat1.device)
         return ops.EpipolarAttend.apply(feat1, feat2, cam, self.layer_spec())
 
-    def _finalize(self, out, feat1=None):
-        """z / bn / ZRESIDUAL (epipolar.py:249-255) and, when feat1 is given, the
-        residual fusion of resnet.py:388 in the same pass.  Returns (finalout, x|None)."""
+    def _folded_z(self):
+        """Eval-mode algebra of epipolar.py:250-253: bn(z(out)) [+ out] == out @ Wf^T + bf with
+        Wf = diag(s) W [+ I], bf = s * b + (beta - mean * s), s = gamma / sqrt(var + eps)."""
+        w = self.z.weight.view(self.z.out_channels, self.z.in_channels)
+        scale = self.bn.weight * torch.rsqrt(self.bn.running_var + self.bn.eps)
+        wf = w * scale[:, None]
+        if self.cfg.EPIPOLAR.ZRESIDUAL:
+            wf = wf + torch.eye(w.shape[0], dtype=w.dtype, device=w.device)
+        bf = self.z.bias * scale + (self.bn.bias - self.bn.running_mean * scale)
+        return wf.t().contiguous(), bf.contiguous()
+
+    def _eval_fast_path(self, tensors):
         cfg = self.cfg
+        if not bool(amd_knob(cfg, "FUSED_EPILOGUE", True)):
+            return False
         has_z = "z" in cfg.EPIPOLAR.PARAMETERIZED
-        grad_mode = torch.is_grad_enabled() and (out.requires_grad or (has_z and self.z.weight.requires_grad))
-        fused_ok = bool(amd_knob(cfg, "FUSED_EPILOGUE", True)) and not grad_mode and \
-            not (has_z and self.bn.training) and (not has_z or cfg.EPIPOLAR.ZRESIDUAL)
-        if not fused_ok:
-            # training (batch statistics / autograd): plain torch ops on the kernel's output
-            finalout = out
-            if has_z:
-                finalout = self.bn(self.z(out))
-                if cfg.EPIPOLAR.ZRESIDUAL:
-                    finalout = finalout + out
-            return finalout, (finalout + feat1 if feat1 is not None else None)
-        out_l = ops.to_nhwc(out)
-        feat_l = ops.to_nhwc(feat1) if feat1 is not None else None
-        if has_z:
-            y = ops.to_nhwc(self.z(out))                     # 1x1 conv = GEMM (MIOpen / hipBLASLt, MFMA)
-            inv = torch.rsqrt(self.bn.running_var + self.bn.eps)
-            scale = (self.bn.weight * inv).contiguous()
-            shift = (self.bn.bias - self.bn.running_mean * scale).contiguous()
-            fin, x = ops.residual_epilogue(feat_l, out_l, y, scale, shift, True, feat_l is not None)
-        else:
-            fin, x = ops.residual_epilogue(feat_l, out_l, None, None, None, feat_l is None, feat_l is not None)
-            fin = fin if fin is not None else out_l
-        to_logical = lambda t: t.permute(0, 3, 1, 2) if t is not None else None
-        return to_logical(fin), to_logical(x)
+        if torch.is_grad_enabled() and (any(t.requires_grad for t in tensors) or
+                                        (has_z and self.z.weight.requires_grad)):
+            return False
+        return not (has_z and self.bn.training)
+
+    def _epilogue_torch(self, out, feat1=None):
+        """Training path (batch statistics / autograd): the reference's own op sequence."""
+        finalout = out
+        if "z" in self.cfg.EPIPOLAR.PARAMETERIZED:
+            finalout = self.bn(self.z(out))                                  # epipolar.py:250-251
+            if self.cfg.EPIPOLAR.ZRESIDUAL:
+                finalout = finalout + out                                    # epipolar.py:253
+        return finalout, (finalout + feat1 if feat1 is not None else None)  # resnet.py:388
 
     def forward(self, feat1, feat2, P1, P2, depth=None, camera=None, other_camera=None, ref1=None, ref2=None):
         """Same contract as the reference (epipolar.py:82-269):
@@ -137,7 +137,13 @@ class Epipolar(nn.Module):
         returns (finalout, corr_pos[N,H,W,2], depth[N,K,H,W], sample_locs | None)."""
         self._check_mode(depth, ref1, ref2)
         out, attn, corr_pos = self.attend(feat1, feat2, P1, P2)
-        finalout, _ = self._finalize(out)
+        if self._eval_fast_path((feat1, feat2)) and "z" in self.cfg.EPIPOLAR.PARAMETERIZED:
+            # one GEMM (hipBLASLt, fp32 MFMA) with the bias in its epilogue
+            wt, bf = self._folded_z()
+            o = ops.to_nhwc(out)
+            finalout = torch.addmm(bf, o.reshape(-1, o.shape[-1]), wt).view_as(o).permute(0, 3, 1, 2)
+        else:
+            finalout, _ = self._epilogue_torch(out)
         sample_locs = None
         if self.debug or self.cfg.VIS.EPIPOLAR_LINE:
             cam = self._cams.get(P1, P2, feat1.device)
@@ -147,9 +153,23 @@ class Epipolar(nn.Module):
         return finalout, corr_pos, attn, sample_locs
 
     def forward_fused(self, feat1, feat2, P1, P2):
-        """forward + `ret + feat` (resnet.py:388) with the adds fused into the
-        epilogue kernel.  Returns (x, corr_pos, depth, None)."""
+        """forward + `ret + feat` (resnet.py:388).  In eval mode the whole epilogue is ONE GEMM: the fused
+        kernel also emits feat + bf while the reference row is in registers, and
+        x = (feat + bf) + out @ Wf^T accumulates into it.  Returns (x, corr_pos, depth, None)."""
         self._check_mode(None, None, None)
-        out, attn, corr_pos = self.attend(feat1, feat2, P1, P2)
-        finalout, x = self._finalize(out, feat1)
-        return x, corr_pos, attn, None
+        if not self._eval_fast_path((feat1, feat2)):
+            out, attn, corr_pos = self.attend(feat1, feat2, P1, P2)
+            _, x = self._epilogue_torch(out, feat1)
+            return x, corr_pos, attn, None
+        cam = self._cams.get(P1, P2, feat1.device)
+        ref, src = ops.to_nhwc(feat1), ops.to_nhwc(feat2)
+        if "z" in self.cfg.EPIPOLAR.PARAMETERIZED:
+            wt, bf = self._folded_z()
+            out, attn, corr_pos, base = ops.forward_nhwc(self.layer_spec(), ref, src, cam, res_bias=bf,
+                                                         want_res_base=True)
+            c = out.shape[-1]
+            x = torch.addmm(base.view(-1, c), out.view(-1, c), wt, out=base.view(-1, c)).view_as(out)
+        else:
+            out, attn, corr_pos = ops.forward_nhwc(self.layer_spec(), ref, src, cam)
+            _, x = ops.residual_epilogue(ref, out, None, None, None, False, True)
+        return x.permute(0, 3, 1, 2), corr_pos, attn, None

@@ -121,8 +121,9 @@ def sample_locs(spec: LayerSpec, cam: torch.Tensor) -> torch.Tensor:
 
 
 def forward_nhwc(spec: LayerSpec, ref: torch.Tensor, src: torch.Tensor, cam: torch.Tensor,
-                 want_attn=True, want_corr=True):
-    """ref/src: (N,H,W,C) contiguous.  Returns out (N,H,W,C), attn (N,K,H,W)|None, corr_pos (N,H,W,2)|None."""
+                 want_attn=True, want_corr=True, res_bias=None, want_res_base=False):
+    """ref/src: (N,H,W,C) contiguous.  Returns out (N,H,W,C), attn (N,K,H,W)|None, corr_pos (N,H,W,2)|None
+    [, res_base (N,H,W,C) = ref + res_bias when want_res_base]."""
     for t, nm in ((ref, "feat_ref"), (src, "feat_src"), (cam, "cam")):
         _require_gpu(t, nm)
     n, h, w, c = ref.shape
@@ -136,11 +137,17 @@ def forward_nhwc(spec: LayerSpec, ref: torch.Tensor, src: torch.Tensor, cam: tor
     out = torch.empty_like(ref)
     attn = torch.empty((n, spec.K, h, w), dtype=torch.float32, device=ref.device) if want_attn else None
     corr = torch.empty((n, h, w, 2), dtype=torch.float32, device=ref.device) if want_corr else None
+    base = torch.empty_like(ref) if want_res_base else None
+    if res_bias is not None:
+        assert want_res_base and res_bias.is_cuda and res_bias.numel() == c and res_bias.is_contiguous()
     d = spec.desc(n, c)
     with torch.cuda.device(ref.device):
         _lib.check(_lib.load().et_epipolar_forward(ctypes.byref(d), _ptr(xs), _ptr(ys), _ptr(steps), _ptr(cam),
                                                    _ptr(ref), _ptr(src), _ptr(out), _ptr(attn), _ptr(corr),
-                                                   _stream(ref)), "et_epipolar_forward")
+                                                   _ptr(res_bias), _ptr(base), _stream(ref)),
+                   "et_epipolar_forward")
+    if want_res_base:
+        return out, attn, corr, base
     return out, attn, corr
 
 

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define ET_ABI_VERSION 1
+#define ET_ABI_VERSION 2
 
 /* Static description of one layer call: the cfg keys the reference reads in
  * Epipolar.__init__ (epipolar.py:12-54) and at call time (epipolar.py:303-311,
@@ -91,10 +91,15 @@ int et_sample_locs(const EtLayerDesc *desc, const float *xs, const float *ys, co
  *   feat_ref, feat_src : (N,H,W,C)
  *   out                : (N,H,W,C)  sum_k attn_k * sampled_k           (epipolar.py:243)
  *   attn      nullable : (N,K,H,W)  the reference's `depth` return     (epipolar.py:263)
- *   corr_pos  nullable : (N,H,W,2)  de-normalised arg-max sample       (epipolar.py:237-242) */
+ *   corr_pos  nullable : (N,H,W,2)  de-normalised arg-max sample       (epipolar.py:237-242)
+ *   res_base  nullable : (N,H,W,C)  feat_ref + res_bias[c] (res_bias nullable = 0): the additive
+ *                        term of the residual fusion, written while the reference row is in
+ *                        registers.  With eval-mode BN folded into z, `ret + feat` (resnet.py:388,
+ *                        epipolar.py:250-253) is then ONE GEMM:  x = res_base + (I + W') out . */
 int et_epipolar_forward(const EtLayerDesc *desc, const float *xs, const float *ys, const float *steps,
                         const float *cam, const float *feat_ref, const float *feat_src, float *out,
-                        float *attn, float *corr_pos, void *stream);
+                        float *attn, float *corr_pos, const float *res_bias, float *res_base,
+                        void *stream);
 
 /* Backward of et_epipolar_forward w.r.t. both feature maps (sample locations
  * carry no gradient, epipolar.py:178-183).  Everything is recomputed from the

@@ -47,10 +47,10 @@ def test_struct_layout_matches_header():
 
 def test_validation_errors_are_reported(lib):
     d = ops.LayerSpec(H=8, W=8, K=8).desc(N=1, C=6)          # C not a multiple of 4
-    rc = lib.et_epipolar_forward(ctypes.byref(d), *[ctypes.c_void_p(0)] * 10)
+    rc = lib.et_epipolar_forward(ctypes.byref(d), *[ctypes.c_void_p(0)] * 12)
     assert rc != 0 and b"multiple of 4" in lib.et_last_error()
     d = ops.LayerSpec(H=8, W=8, K=8).desc(N=1, C=8)
-    rc = lib.et_epipolar_forward(ctypes.byref(d), *[ctypes.c_void_p(0)] * 10)
+    rc = lib.et_epipolar_forward(ctypes.byref(d), *[ctypes.c_void_p(0)] * 12)
     assert rc != 0 and b"NULL" in lib.et_last_error()
 
 
