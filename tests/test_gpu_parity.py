@@ -181,13 +181,16 @@ def test_module_dropin_eval_and_train(env, case):
                                   d["bn_running_mean"], d["bn_running_var"], training=tr)[0].numpy()
         d["sample_locs"] = w["sample_locs"][:, :, d["rows"]]
         d["grad_feat1"], d["grad_feat2"] = orc.backward(so, d["feat1"], d["feat2"], w["sample_locs"], d["grad_out"])
-    _close(fin.cpu().numpy(), d["finalout_eval"], TOL_OUT)
-    _close(x.cpu().numpy(), d["finalout_eval"] + d["feat1"], TOL_OUT)     # resnet.py:388
+    # with the soft-max off a masked sample keeps its -1e10/K weight: |out| reaches 1e9 and the z/BN
+    # epilogue cancels it by orders of magnitude -- hold that case to float32 noise of the operands
+    tol_fin = TOL_OUT if m["softmax"] else 2e-6 * float(np.abs(d["out"]).max())
+    _close(fin.cpu().numpy(), d["finalout_eval"], tol_fin)
+    _close(x.cpu().numpy(), d["finalout_eval"] + d["feat1"], tol_fin)      # resnet.py:388
     assert np.array_equal(locs.cpu().numpy().transpose(1, 0, 2, 3, 4)[:, :, d["rows"]], d["sample_locs"])
     mod.train()
     with torch.no_grad():
         fin_t, _, _, _ = mod(f1, f2, P1, P2)
-    _close(fin_t.cpu().numpy(), d["finalout_train"], TOL_OUT, rtol=1e-5)
+    _close(fin_t.cpu().numpy(), d["finalout_train"], tol_fin, rtol=1e-5)
     # batch statistics are sums over N*H*W values; with the soft-max off a masked sample keeps its
     # -1e10/K weight, the sums cancel by ~3 orders of magnitude and carry that much float32 noise
     _close(mod.bn.running_mean.cpu().numpy(), d["bn_running_mean_after"], 1e-5, rtol=1e-5 if m["softmax"] else 2e-3)
