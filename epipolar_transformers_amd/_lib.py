@@ -22,6 +22,9 @@ ET_VARIANT_OCC6 = 32
 ET_VARIANT_ABLATE_NO_LOADS = 64
 ET_VARIANT_ABLATE_ONE_ROW = 128
 ET_VARIANT_BASELINE = 256
+ET_VARIANT_PIPELINE = 512
+ET_VARIANT_MULTI2 = 1024
+ET_VARIANT_MULTI4 = 2048
 ET_ABI_VERSION = 2
 
 

@@ -604,6 +604,264 @@ __global__ __launch_bounds__(kWave *kWavesPerBlock, MINW) void epipolar_fwd_kern
 }
 
 // ----------------------------------------------------------------------------
+// forward, several pixels per wave ("multi"): PPW neighbouring pixels advance in
+// lockstep, LPP = 64 / PPW lanes each, CQ float4 channel groups per lane.
+// ----------------------------------------------------------------------------
+// Why: in the one-pixel-per-wave kernel only ~13 of ~36 VALU instructions per sample
+// are arithmetic; the rest is per-sample bookkeeping (lane broadcasts, 64-lane
+// reductions, soft-max updates) that here is issued once per step for PPW pixels:
+// the per-step record (tap offsets, weights, need bits) is read from LDS by each
+// lane group, tap loads are exec-masked per group, the dot product reduces over
+// LPP lanes only, and the online soft-max runs one sample per step (no batching).
+// Requires C == 4 * LPP * CQ exactly (C = 256: PPW 2 / CQ 2 or PPW 4 / CQ 4).
+template <int PPW, int CQ, int KPL, bool PIPE>
+__global__ __launch_bounds__(kWave *kWavesPerBlock) void epipolar_fwd_multi_kernel(const FwdParams p)
+{
+    constexpr int LPP = kWave / PPW;
+    constexpr int ROUNDS = kPixPerWave / PPW;
+    constexpr int KP = KPL * kWave;  // padded samples per pixel
+    extern __shared__ float s_dyn[];
+    const EtLayerDesc &d = p.d;
+    const int H = d.H, W = d.W, C = d.C, K = d.K;
+    const int HW = H * W;
+
+    const int vb = xcd_remap(blockIdx.x, p.total_blocks);
+    const int n = vb / p.blocks_per_pair;
+    const int pb = vb - n * p.blocks_per_pair;
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int pix_base = pb * kPixPerBlock;
+    const int g = lane / LPP, li = lane % LPP;
+
+    // LDS carve-up: attention tile, then per wave: offsets, weights, need bits, logits, segments
+    float *s_attn = s_dyn;
+    char *wbase = reinterpret_cast<char *>(s_dyn + (p.attn ? K * kPixPerBlock : 0)) +
+                  (size_t)wave * (PPW * KP * 40 + PPW * 16);
+    int4 *s_off = reinterpret_cast<int4 *>(wbase);                       // [PPW][KP]
+    float4 *s_wt = reinterpret_cast<float4 *>(wbase + PPW * KP * 16);    // [PPW][KP]
+    int *s_need = reinterpret_cast<int *>(wbase + PPW * KP * 32);        // [PPW][KP]
+    float *s_sim = reinterpret_cast<float *>(wbase + PPW * KP * 36);     // [PPW][KP]
+    float4 *s_seg = reinterpret_cast<float4 *>(wbase + PPW * KP * 40);   // [PPW]
+
+    const float *cam = p.cam + (size_t)n * ET_CAM_STRIDE;
+    const __amdgpu_buffer_rsrc_t src = make_rsrc(p.fsrc + (size_t)n * HW * C, (unsigned)HW * C * 4u);
+    const int row_bytes = C * 4;
+    const float neg_inf = -__builtin_huge_valf();
+    const int lane_off = li * 16;  // + c * LPP * 16 as the instruction's immediate offset
+
+    for (int round = 0; round < ROUNDS; ++round) {
+        const int first = pix_base + wave * kPixPerWave + round * PPW;  // first pixel of this wave's group
+        if (first >= HW) break;                                         // wave-uniform
+        // ---- lanes <-> samples, one pixel after the other: records into LDS ----
+#pragma unroll
+        for (int gg = 0; gg < PPW; ++gg) {
+            const int pix = first + gg;
+            const bool live = pix < HW;
+            const int pc = live ? pix : HW - 1;
+            const int h = pc / W, w = pc - h * W;
+            const et::Segment seg = et::epipolar_segment(d, cam, p.xs[w], p.ys[h]);
+            SampleTable<KPL> tb;
+            build_sample_table<KPL, true>(d, seg, p.steps, lane, row_bytes, tb);
+#pragma unroll
+            for (int s = 0; s < KPL; ++s) {
+                const int k = s * kWave + lane;
+                s_off[gg * KP + k] = make_int4(tb.off[s][0], tb.off[s][1], tb.off[s][2], tb.off[s][3]);
+                s_wt[gg * KP + k] = make_float4(tb.w[s][0], tb.w[s][1], tb.w[s][2], tb.w[s][3]);
+                s_need[gg * KP + k] = live ? tb.need[s] : 0;
+            }
+            if (lane == 0) s_seg[gg] = make_float4(seg.sx, seg.sy, seg.vx, seg.vy);
+        }
+        __builtin_amdgcn_wave_barrier();
+
+        // ---- lanes <-> (pixel, channels) ------------------------------------------
+        const int mypix = first + g;
+        const bool mylive = mypix < HW;
+        float4 f1[CQ], acc[CQ], R[4][CQ];
+        const float4 *ref = reinterpret_cast<const float4 *>(p.fref + ((size_t)n * HW + (mylive ? mypix : 0)) * C);
+#pragma unroll
+        for (int c = 0; c < CQ; ++c) {
+            f1[c] = mylive ? ref[c * LPP + li] : f4_zero();
+            acc[c] = f4_zero();
+#pragma unroll
+            for (int r = 0; r < 4; ++r) R[r][c] = f4_zero();
+        }
+        if (p.res_base && mylive) {
+            float4 *b4 = reinterpret_cast<float4 *>(p.res_base + ((size_t)n * HW + mypix) * C);
+            const float4 *bias4 = reinterpret_cast<const float4 *>(p.res_bias);
+#pragma unroll
+            for (int c = 0; c < CQ; ++c) {
+                float4 r = f1[c];
+                if (bias4) {
+                    const float4 bb = bias4[c * LPP + li];
+                    r = make_float4(r.x + bb.x, r.y + bb.y, r.z + bb.z, r.w + bb.w);
+                }
+                b4[c * LPP + li] = r;
+            }
+        }
+        float m_run = neg_inf;
+        const int rec0 = g * KP;
+
+        // request (exec-masked per lane group) the tap rows step k does not have yet
+        auto issue_step = [&](int k) {
+            const int need = (p.ablate == 1 && k > 0) ? 0 : s_need[rec0 + k];
+            const int4 off = s_off[rec0 + k];
+            if (need & 1) {
+#pragma unroll
+                for (int c = 0; c < CQ; ++c) R[0][c] = buf_load_f4(src, off.x + lane_off + c * LPP * 16, 0);
+            }
+            if (need & 2) {
+#pragma unroll
+                for (int c = 0; c < CQ; ++c) R[1][c] = buf_load_f4(src, off.y + lane_off + c * LPP * 16, 0);
+            }
+            if (need & 4) {
+#pragma unroll
+                for (int c = 0; c < CQ; ++c) R[2][c] = buf_load_f4(src, off.z + lane_off + c * LPP * 16, 0);
+            }
+            if (need & 8) {
+#pragma unroll
+                for (int c = 0; c < CQ; ++c) R[3][c] = buf_load_f4(src, off.w + lane_off + c * LPP * 16, 0);
+            }
+        };
+        if (PIPE) issue_step(0);
+        for (int k = 0; k < K; ++k) {
+            if (!PIPE) issue_step(k);
+            const float4 wv = s_wt[rec0 + k];
+            float4 S[CQ];
+            float part = 0.f;
+#pragma unroll
+            for (int c = 0; c < CQ; ++c) {
+                float4 sv = f4_mul(wv.x, R[0][c]);
+                sv = f4_fma(wv.y, R[1][c], sv);
+                sv = f4_fma(wv.z, R[2][c], sv);
+                sv = f4_fma(wv.w, R[3][c], sv);
+                S[c] = sv;
+            }
+            if (PIPE) {
+                // the next step's rows fly during this step's dot product, reduction and soft-max update
+                __builtin_amdgcn_sched_barrier(0);
+                if (k + 1 < K) issue_step(k + 1);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int c = 0; c < CQ; ++c) part = (c == 0) ? f4_dot(S[c], f1[c]) : part + f4_dot(S[c], f1[c]);
+            // all-reduce over the LPP lanes of the pixel
+            part += dpp<0x128>(part);  // row_ror:8
+            part += dpp<0x124>(part);  // row_ror:4
+            part += dpp<0x122>(part);  // row_ror:2
+            part += dpp<0x121>(part);  // row_ror:1
+            if (LPP == 32) part += __shfl_xor(part, 16);
+            float sv = (part == 0.f) ? -1e10f : part;  // epipolar.py:298
+            float e;
+            if (d.softmax_enabled) {
+                sv = sv * d.softmax_scale;  // epipolar.py:306
+                const float m_new = fmaxf(m_run, sv);
+                if (__any(m_new > m_run)) {  // rare after the first few samples
+                    const float alpha = __expf(m_run - m_new);
+#pragma unroll
+                    for (int c = 0; c < CQ; ++c) acc[c] = f4_mul(alpha, acc[c]);
+                }
+                m_run = m_new;
+                e = __expf(sv - m_new);
+            } else {
+                sv = sv / (float)K;  // epipolar.py:311
+                e = sv;
+            }
+            s_sim[rec0 + k] = sv;
+#pragma unroll
+            for (int c = 0; c < CQ; ++c) acc[c] = f4_fma(e, S[c], acc[c]);
+        }
+        __builtin_amdgcn_wave_barrier();
+
+        // ---- lanes <-> samples per pixel: exact soft-max, arg-max, outputs ----------
+        float my_scale = 1.f;
+#pragma unroll
+        for (int gg = 0; gg < PPW; ++gg) {
+            const int pix = first + gg;
+            if (pix >= HW) break;  // wave-uniform
+            const float m_g = lane_bcast(m_run, gg * LPP);
+            float a[KPL];
+            float denom = 1.f;
+            if (d.softmax_enabled) {
+                float lsum = 0.f;
+#pragma unroll
+                for (int s = 0; s < KPL; ++s) {
+                    const int k = s * kWave + lane;
+                    a[s] = (k < K) ? expf(s_sim[gg * KP + k] - m_g) : 0.f;
+                    lsum += a[s];
+                }
+                denom = wave_sum(lsum);
+#pragma unroll
+                for (int s = 0; s < KPL; ++s) a[s] = a[s] / denom;
+                if (g == gg) my_scale = 1.f / denom;
+            } else {
+#pragma unroll
+                for (int s = 0; s < KPL; ++s) a[s] = (s * kWave + lane < K) ? s_sim[gg * KP + s * kWave + lane] : 0.f;
+            }
+            float bestv = neg_inf;
+            int besti = 0x7fffffff;
+#pragma unroll
+            for (int s = 0; s < KPL; ++s) {
+                const int k = s * kWave + lane;
+                if (k < K && (a[s] > bestv)) {
+                    bestv = a[s];
+                    besti = k;
+                }
+            }
+#pragma unroll
+            for (int m = 32; m >= 1; m >>= 1) {
+                const float ov = __shfl_xor(bestv, m);
+                const int oi = __shfl_xor(besti, m);
+                if (ov > bestv || (ov == bestv && oi < besti)) {
+                    bestv = ov;
+                    besti = oi;
+                }
+            }
+            if (p.corr && lane == 0) {
+                const float4 sg = s_seg[gg];
+                et::Segment seg;
+                seg.sx = sg.x; seg.sy = sg.y; seg.vx = sg.z; seg.vy = sg.w;
+                const et::SampleSetup su = et::sample_setup(d, seg, p.steps[besti]);
+                float *o = p.corr + ((size_t)n * HW + pix) * 2;
+                o[0] = et::de_normalize(d, su.nx, W);
+                o[1] = et::de_normalize(d, su.ny, H);
+            }
+            if (p.attn) {
+                const int slot_in_block = wave * kPixPerWave + round * PPW + gg;
+#pragma unroll
+                for (int s = 0; s < KPL; ++s) {
+                    const int k = s * kWave + lane;
+                    if (k < K) s_attn[k * kPixPerBlock + slot_in_block] = a[s];
+                }
+            }
+        }
+        if (mylive) {
+            float4 *o4 = reinterpret_cast<float4 *>(p.out + ((size_t)n * HW + mypix) * C);
+#pragma unroll
+            for (int c = 0; c < CQ; ++c) o4[c * LPP + li] = f4_mul(my_scale, acc[c]);
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+
+    if (p.attn) {
+        __syncthreads();
+        const int npix = min(kPixPerBlock, HW - pix_base);
+        float *dst = p.attn + (size_t)n * K * HW + pix_base;
+        if (npix == kPixPerBlock && (HW & 3) == 0) {
+            for (int t = threadIdx.x; t < K * 4; t += blockDim.x) {
+                const int k = t >> 2, q = t & 3;
+                const float4 v = *reinterpret_cast<const float4 *>(&s_attn[k * kPixPerBlock + q * 4]);
+                *reinterpret_cast<float4 *>(dst + (size_t)k * HW + q * 4) = v;
+            }
+        } else {
+            for (int t = threadIdx.x; t < K * kPixPerBlock; t += blockDim.x) {
+                const int k = t / kPixPerBlock, i = t % kPixPerBlock;
+                if (i < npix) dst[(size_t)k * HW + i] = s_attn[k * kPixPerBlock + i];
+            }
+        }
+    }
+}
+
+// ----------------------------------------------------------------------------
 // backward
 // ----------------------------------------------------------------------------
 // Same walk, twice.  Pass A recomputes the logits and da_k = g . S_k; the
@@ -1006,13 +1264,34 @@ int et_epipolar_forward(const EtLayerDesc *desc, const float *xs, const float *y
                        (size_t)kWavesPerBlock * kpl_ * kWave * 4 * sizeof(float);
     hipStream_t st = (hipStream_t)stream;
     const int cpl = (desc->C + 255) / 256, kpl = (desc->K + 63) / 64;
-    // variant 0 = the tuned default (measured on MI355X, profiles/): batches of 4 samples,
-    // <= 96 VGPRs (5 waves/SIMD), waves of a block interleaved over neighbouring pixels
+    // variant 0 = the tuned default (measured on MI355X, profiles/): for the 256-channel head four pixels
+    // per wave in lockstep; otherwise one pixel per wave, batches of 4 samples, <= 96 VGPRs (5 waves/SIMD),
+    // waves of a block interleaved over neighbouring pixels
     int v = desc->variant;
     if ((v & ~(ET_VARIANT_ABLATE_NO_LOADS | ET_VARIANT_ABLATE_ONE_ROW)) == 0)
-        v |= ET_VARIANT_BATCH4 | ET_VARIANT_OCC5 | ET_VARIANT_PIXEL_INTERLEAVE;
-    if (v & ET_VARIANT_BASELINE) v &= ~(ET_VARIANT_BATCH4 | ET_VARIANT_OCC5 | ET_VARIANT_OCC6 | ET_VARIANT_PIXEL_INTERLEAVE);
+        v |= (desc->C == 256 && kpl <= 2) ? ET_VARIANT_MULTI4
+                                          : (ET_VARIANT_BATCH4 | ET_VARIANT_OCC5 | ET_VARIANT_PIXEL_INTERLEAVE);
+    if (v & ET_VARIANT_BASELINE)
+        v &= ~(ET_VARIANT_BATCH4 | ET_VARIANT_OCC5 | ET_VARIANT_OCC6 | ET_VARIANT_PIXEL_INTERLEAVE |
+               ET_VARIANT_MULTI2 | ET_VARIANT_MULTI4);
+    p.ablate = (v & ET_VARIANT_ABLATE_NO_LOADS) ? 1 : (v & ET_VARIANT_ABLATE_ONE_ROW) ? 2 : 0;
     p.interleave = (v & ET_VARIANT_PIXEL_INTERLEAVE) ? 1 : 0;
+    if ((v & (ET_VARIANT_MULTI2 | ET_VARIANT_MULTI4)) && desc->C == 256 && kpl <= 2) {
+        // several pixels per wave; per-wave LDS: PPW * KP * 40 + PPW * 16 bytes
+        const int ppw = (v & ET_VARIANT_MULTI4) ? 4 : 2;
+        const size_t lds_m = (attn ? (size_t)desc->K * kPixPerBlock * sizeof(float) : 0) +
+                             (size_t)kWavesPerBlock * (ppw * kpl * kWave * 40 + ppw * 16);
+        const bool pipe = v & ET_VARIANT_PIPELINE;
+#define ET_MULTI(P, Q, KK)                                                                                     \
+    do {                                                                                                       \
+        if (pipe) hipLaunchKernelGGL((epipolar_fwd_multi_kernel<P, Q, KK, true>), grid, dim3(256), lds_m, st, p);  \
+        else hipLaunchKernelGGL((epipolar_fwd_multi_kernel<P, Q, KK, false>), grid, dim3(256), lds_m, st, p);      \
+    } while (0)
+        if (ppw == 4) { if (kpl == 1) ET_MULTI(4, 4, 1); else ET_MULTI(4, 4, 2); }
+        else { if (kpl == 1) ET_MULTI(2, 2, 1); else ET_MULTI(2, 2, 2); }
+#undef ET_MULTI
+        return check_launch("et_epipolar_forward(multi)");
+    }
     if (cpl == 1) {
         if (kpl == 1) launch_fwd<1, 1>(p, v, grid, lds, st);
         else if (kpl == 2) launch_fwd<1, 2>(p, v, grid, lds, st);

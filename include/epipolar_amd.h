@@ -62,13 +62,17 @@ typedef struct EtLayerDesc {
 #define ET_CAM_STRIDE 27
 
 /* Variant bits (EtLayerDesc.variant).  0 selects the tuned default of the forward kernel
- * (= BATCH4 | OCC5 | PIXEL_INTERLEAVE); the bits exist for ablation and tuning runs. */
+ * (MULTI4 for C == 256 and K <= 128, else BATCH4 | OCC5 | PIXEL_INTERLEAVE); the bits exist
+ * for ablation and tuning runs. */
 #define ET_VARIANT_SAFE_REDUCE 1  /* cross-lane sums via ds_bpermute only (no permlane swaps / DPP) */
 #define ET_VARIANT_NO_TAP_CACHE 2 /* reload all four taps for every sample                          */
 #define ET_VARIANT_PIXEL_INTERLEAVE 4 /* wave w of a block takes pixels w, w+4, .. instead of 4w..4w+3 */
 #define ET_VARIANT_BATCH4 8       /* cross-lane reductions per 4 samples (fewer registers) instead of 8 */
 #define ET_VARIANT_OCC5 16        /* compile for >= 5 waves per SIMD (<= 96 VGPRs)                       */
 #define ET_VARIANT_OCC6 32        /* compile for >= 6 waves per SIMD (<= 80 VGPRs, may spill)            */
+#define ET_VARIANT_PIPELINE 512    /* multi kernels: request step k+1's rows right after step k is interpolated */
+#define ET_VARIANT_MULTI2 1024     /* C == 256: two pixels per wave in lockstep (32 lanes x 8 channels each) */
+#define ET_VARIANT_MULTI4 2048     /* C == 256: four pixels per wave in lockstep (16 lanes x 16 channels)    */
 #define ET_VARIANT_BASELINE 256    /* batches of 8, compiler-chosen registers, pixels 4w..4w+3 per wave   */
 #define ET_VARIANT_ABLATE_NO_LOADS 64  /* profiling only, WRONG RESULTS: no tap loads after the first sample */
 #define ET_VARIANT_ABLATE_ONE_ROW 128  /* profiling only, WRONG RESULTS: every tap load reads source row 0    */

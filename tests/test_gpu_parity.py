@@ -228,7 +228,8 @@ def _full_inputs(frames, views, H, C, image, seed):
 @pytest.mark.parametrize("shape", [dict(H=64, C=256, K=64, image=256, views=4, name="config2 R50 256x256"),
                                    dict(H=96, C=256, K=64, image=384, views=4, name="config4 R152 384x384"),
                                    dict(H=128, C=256, K=128, image=512, views=8, name="config5 stress")])
-def test_full_shape_pairs_vs_oracle(env, oracle_mod, shape):
+@pytest.mark.parametrize("variant", [0, 28, 1024, 2048, 256])
+def test_full_shape_pairs_vs_oracle(env, oracle_mod, shape, variant):
     """BASELINE.json configs 2/4/5 at their real C, HxW and K, on a few pairs the
     oracle finishes in seconds (full tensors compared)."""
     _lib, camera, ops = env
@@ -236,10 +237,12 @@ def test_full_shape_pairs_vs_oracle(env, oracle_mod, shape):
     P1, P2, f1, f2 = _full_inputs(1, shape["views"], H, C, shape["image"], seed=11)
     P1, P2, f1, f2 = P1[:2], P2[:2], f1[:2], f2[:2]
     f1[0, :, 5, 7] = 0
-    spec = ops.LayerSpec(H=H, W=H, K=K)
+    spec = ops.LayerSpec(H=H, W=H, K=K, variant=variant)     # 0: default (4 pixels/wave at C=256), 28: 1 pixel/wave
     cam = camera.pair_algebra(P1, P2).cuda()
     ref, src = ops.to_nhwc(f1.cuda()), ops.to_nhwc(f2.cuda())
-    out, attn, corr = ops.forward_nhwc(spec, ref, src, cam)
+    bias = torch.linspace(-1, 1, C, device="cuda")
+    out, attn, corr, base = ops.forward_nhwc(spec, ref, src, cam, res_bias=bias, want_res_base=True)
+    assert torch.equal(base, ref + bias)                     # additive term of the residual fusion
     want = oracle_mod.forward(oracle_mod.LayerSpec(H, H, K), f1, f2, None, None, cam=cam.cpu().numpy())
     _close(attn.cpu().numpy(), want["attn"], TOL_ATTN)
     _close(out.permute(0, 3, 1, 2).cpu().numpy(), want["out"], TOL_OUT)
@@ -273,7 +276,7 @@ def test_config2_full_batch_properties(env):
     out2, attn2, corr2 = ops.forward_nhwc(spec, ref, src, cam)
     assert torch.equal(out, out2) and torch.equal(attn, attn2) and torch.equal(corr, corr2)
     # (3) all variants agree
-    for v in (1, 2, 3):
+    for v in (1, 2, 3, 28, 1024, 2048, 256):
         spec_v = ops.LayerSpec(H=64, W=64, K=64, variant=v)
         out_v, attn_v, _ = ops.forward_nhwc(spec_v, ref, src, cam)
         assert (out_v - out).abs().max().item() <= 1e-5 and (attn_v - attn).abs().max().item() <= 1e-6
