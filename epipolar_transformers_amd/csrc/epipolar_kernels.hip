@@ -21,6 +21,7 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <cstdint>
 #include <cstring>
 
 #include "epipolar_amd.h"
@@ -78,6 +79,13 @@ struct BwdParams {
     float *gref, *gsrc;
     int blocks_per_pair;
     int total_blocks;
+    // gather-form backward (workspace given): per-(pixel, source row) coefficient entries
+    int cap;            // entry slots per reference pixel (4 * K)
+    int *ent_u;         // [N*HW*cap] source pixel index of the entry
+    float *ent_a;       // [N*HW*cap] alpha = sum_k w_ku a_k      (value path,      OTHER_GRAD 'other2')
+    float *ent_b;       // [N*HW*cap] beta  = sum_k w_ku ds_k     (similarity path, OTHER_GRAD 'other1')
+    int *ent_count;     // [N*HW]     entries emitted by each reference pixel
+    int *row_count;     // [N*HW]     entries received by each source pixel (zeroed per call)
 };
 
 // ----------------------------------------------------------------------------
@@ -871,9 +879,13 @@ __global__ __launch_bounds__(kWave *kWavesPerBlock) void epipolar_fwd_multi_kern
 // is evicted, i.e. once per (pixel, source row) instead of once per sample.
 // Channel mapping here is lane + 64*i (dword-strided) so that each atomic
 // instruction of a flush covers 256 contiguous bytes.
-template <int CPD /*dwords per lane: C <= 64*CPD*/, int KPL, bool FAST>
+template <int CPD /*dwords per lane: C <= 64*CPD*/, int KPL, bool FAST, bool EMIT>
 __global__ __launch_bounds__(kWave *kWavesPerBlock) void epipolar_bwd_kernel(const BwdParams p)
 {
+    // EMIT: instead of scattering gradient rows with float atomics, emit for every (pixel, source row)
+    // run the two scalars alpha/beta with  d feat_src[u] += alpha * g_p + beta * f_p ; a gather kernel
+    // (epipolar_bwd_gather_kernel) then sums them per source pixel -- no float atomics at all.
+    extern __shared__ float s_dyn[];   // EMIT: per wave [cap] u, [cap] alpha, [cap] beta
     const EtLayerDesc &d = p.d;
     const int H = d.H, W = d.W, C = d.C, K = d.K;
     const int HW = H * W;
@@ -888,6 +900,9 @@ __global__ __launch_bounds__(kWave *kWavesPerBlock) void epipolar_bwd_kernel(con
     const float *cam = p.cam + (size_t)n * ET_CAM_STRIDE;
     const __amdgpu_buffer_rsrc_t src = make_rsrc(p.fsrc + (size_t)n * HW * C, (unsigned)HW * C * 4u);
     const __amdgpu_buffer_rsrc_t gsrc = make_rsrc(p.gsrc + (size_t)n * HW * C, (unsigned)HW * C * 4u);
+    int *s_eu = reinterpret_cast<int *>(s_dyn) + (EMIT ? wave * 3 * p.cap : 0);
+    float *s_ea = reinterpret_cast<float *>(s_eu) + (EMIT ? p.cap : 0);
+    float *s_eb = s_ea + (EMIT ? p.cap : 0);
     const int row_bytes = C * 4;
     const float neg_inf = -__builtin_huge_valf();
     // lanes beyond C (only when C < 64*CPD) alias the last channel: they read
@@ -1025,6 +1040,18 @@ __global__ __launch_bounds__(kWave *kWavesPerBlock) void epipolar_bwd_kernel(con
             }
         }
         int tag[4] = {-1, -1, -1, -1};  // byte offset of the row whose gradient G[r] holds (scalar)
+        float ea[4] = {0.f, 0.f, 0.f, 0.f}, eb[4] = {0.f, 0.f, 0.f, 0.f};  // EMIT: coefficients of that row
+        int ecount = 0;
+        auto emit = [&](int r) {  // wave-uniform call
+            if (lane == 0) {
+                s_eu[ecount] = tag[r] / row_bytes;
+                s_ea[ecount] = ea[r];
+                s_eb[ecount] = eb[r];
+            }
+            ++ecount;
+            ea[r] = 0.f;
+            eb[r] = 0.f;
+        };
 
 #pragma unroll
         for (int s = 0; s < KPL; ++s) {
@@ -1036,10 +1063,14 @@ __global__ __launch_bounds__(kWave *kWavesPerBlock) void epipolar_bwd_kernel(con
                     if (need & (1 << r)) {
                         const int off = __builtin_amdgcn_readlane(tb.off[s][r], kk);
                         if (tag[r] >= 0) {
+                            if (EMIT) {
+                                emit(r);
+                            } else {
 #pragma unroll
-                            for (int c = 0; c < CPD; ++c) {
-                                __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(G[r][c], gsrc, voff[c], tag[r], 0);
-                                G[r][c] = 0.f;
+                                for (int c = 0; c < CPD; ++c) {
+                                    __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(G[r][c], gsrc, voff[c], tag[r], 0);
+                                    G[r][c] = 0.f;
+                                }
                             }
                         }
 #pragma unroll
@@ -1053,6 +1084,12 @@ __global__ __launch_bounds__(kWave *kWavesPerBlock) void epipolar_bwd_kernel(con
                 // OTHER_GRAD (epipolar.py:141-153): which of the two uses of feat_src carry gradient
                 const float ak_src = (d.src_grad_mask & 2) ? ak : 0.f;
                 const float dsk_src = (d.src_grad_mask & 1) ? dsk : 0.f;
+                if (EMIT) {
+                    ea[0] = fmaf(w0, ak_src, ea[0]); eb[0] = fmaf(w0, dsk_src, eb[0]);
+                    ea[1] = fmaf(w1, ak_src, ea[1]); eb[1] = fmaf(w1, dsk_src, eb[1]);
+                    ea[2] = fmaf(w2, ak_src, ea[2]); eb[2] = fmaf(w2, dsk_src, eb[2]);
+                    ea[3] = fmaf(w3, ak_src, ea[3]); eb[3] = fmaf(w3, dsk_src, eb[3]);
+                }
 #pragma unroll
                 for (int c = 0; c < CPD; ++c) {
                     float sv = w0 * R[0][c];
@@ -1060,21 +1097,41 @@ __global__ __launch_bounds__(kWave *kWavesPerBlock) void epipolar_bwd_kernel(con
                     sv = fmaf(w2, R[2][c], sv);
                     sv = fmaf(w3, R[3][c], sv);
                     d1[c] = fmaf(dsk, sv, d1[c]);
-                    const float dS = fmaf(dsk_src, f1[c], ak_src * g[c]);
-                    G[0][c] = fmaf(w0, dS, G[0][c]);
-                    G[1][c] = fmaf(w1, dS, G[1][c]);
-                    G[2][c] = fmaf(w2, dS, G[2][c]);
-                    G[3][c] = fmaf(w3, dS, G[3][c]);
+                    if (!EMIT) {
+                        const float dS = fmaf(dsk_src, f1[c], ak_src * g[c]);
+                        G[0][c] = fmaf(w0, dS, G[0][c]);
+                        G[1][c] = fmaf(w1, dS, G[1][c]);
+                        G[2][c] = fmaf(w2, dS, G[2][c]);
+                        G[3][c] = fmaf(w3, dS, G[3][c]);
+                    }
                 }
             }
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             if (tag[r] >= 0) {
+                if (EMIT) {
+                    emit(r);
+                } else {
 #pragma unroll
-                for (int c = 0; c < CPD; ++c)
-                    __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(G[r][c], gsrc, voff[c], tag[r], 0);
+                    for (int c = 0; c < CPD; ++c)
+                        __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(G[r][c], gsrc, voff[c], tag[r], 0);
+                }
             }
+        }
+        if (EMIT) {
+            // entries of this pixel: LDS -> global (coalesced), and one integer count per target row
+            __builtin_amdgcn_wave_barrier();
+            const size_t ebase = ((size_t)n * HW + pix) * p.cap;
+            for (int i = lane; i < ecount; i += kWave) {
+                const int u = s_eu[i];
+                p.ent_u[ebase + i] = u;
+                p.ent_a[ebase + i] = s_ea[i];
+                p.ent_b[ebase + i] = s_eb[i];
+                atomicAdd(&p.row_count[(size_t)n * HW + u], 1);
+            }
+            if (lane == 0) p.ent_count[(size_t)n * HW + pix] = ecount;
+            __builtin_amdgcn_wave_barrier();
         }
         float *gr = p.gref + ((size_t)n * HW + pix) * C;
 #pragma unroll
@@ -1082,6 +1139,150 @@ __global__ __launch_bounds__(kWave *kWavesPerBlock) void epipolar_bwd_kernel(con
             const int ch = lane + c * kWave;
             if (live[c]) gr[ch] = d1[c];
         }
+    }
+}
+
+// ----------------------------------------------------------------------------
+// gather-form backward of d(feat_src): scan, bucket, gather
+// ----------------------------------------------------------------------------
+// Per pair: exclusive prefix sum of row_count[HW] -> row_base[HW] (one block per pair).
+__global__ __launch_bounds__(256) void bwd_scan_kernel(int HW, const int *row_count, int *row_base, int *row_cursor)
+{
+    __shared__ int s_part[256];
+    const int n = blockIdx.x, t = threadIdx.x;
+    const int *cnt = row_count + (size_t)n * HW;
+    int *base = row_base + (size_t)n * HW;
+    int *cur = row_cursor + (size_t)n * HW;
+    const int per = (HW + 255) / 256;
+    const int lo = t * per, hi = min(HW, lo + per);
+    int sum = 0;
+    for (int i = lo; i < hi; ++i) sum += cnt[i];
+    s_part[t] = sum;
+    __syncthreads();
+    if (t == 0) {
+        int run = 0;
+        for (int i = 0; i < 256; ++i) {
+            const int v = s_part[i];
+            s_part[i] = run;
+            run += v;
+        }
+    }
+    __syncthreads();
+    int run = s_part[t];
+    for (int i = lo; i < hi; ++i) {
+        base[i] = run;
+        cur[i] = 0;
+        run += cnt[i];
+    }
+}
+
+// One thread per entry slot of the pixel-major buffer: move it to its source row's segment.
+__global__ __launch_bounds__(256) void bwd_bucket_kernel(int HW, int cap, size_t total_slots, const int *ent_count,
+                                                          const int *ent_u, const float *ent_a, const float *ent_b,
+                                                          const int *row_base, int *row_cursor, int *csr_p,
+                                                          float *csr_a, float *csr_b)
+{
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total_slots; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t gp = i / cap;  // global reference pixel n*HW + p
+        const int slot = (int)(i - gp * cap);
+        if (slot >= ent_count[gp]) continue;
+        const size_t n = gp / HW;
+        const int pidx = (int)(gp - n * HW);
+        const int u = ent_u[i];
+        const size_t gu = n * HW + u;
+        const int pos = row_base[gu] + atomicAdd(&row_cursor[gu], 1);
+        const size_t o = n * (size_t)HW * cap + pos;  // per-pair CSR region of HW*cap slots
+        csr_p[o] = pidx * cap + slot;                 // unique, run-independent ordering key
+        csr_a[o] = ent_a[i];
+        csr_b[o] = ent_b[i];
+    }
+}
+
+// One wave per source pixel u: d feat_src[u] = sum_e alpha_e * g[p_e] + beta_e * f[p_e].
+// Entries are ordered by reference pixel index first (bitonic sort in LDS) so the float32 sum has a
+// fixed order: the result is bit-reproducible, unlike the atomic scatter.
+template <int CPL>
+__global__ __launch_bounds__(256) void epipolar_bwd_gather_kernel(int HW, int C, int cap, int total_rows, int mask,
+                                                                   const int *row_count, const int *row_base,
+                                                                   const int *csr_p, const float *csr_a,
+                                                                   const float *csr_b, const float *fref,
+                                                                   const float *gout, float *gsrc, int max_sort)
+{
+    extern __shared__ int s_sort[];  // per wave: max_sort keys + max_sort CSR indices
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int gu = xcd_remap(blockIdx.x, gridDim.x) * kWavesPerBlock + wave;  // global source pixel n*HW + u
+    if (gu >= total_rows) return;
+    const int n = gu / HW;
+    const int cnt = row_count[gu];
+    const size_t seg = (size_t)n * HW * cap + row_base[gu];
+    const int nvec = C >> 2;
+    float4 acc[CPL];
+#pragma unroll
+    for (int c = 0; c < CPL; ++c) acc[c] = f4_zero();
+    int voff[CPL];
+#pragma unroll
+    for (int c = 0; c < CPL; ++c) voff[c] = min(lane + c * kWave, nvec - 1);
+
+    // order of summation: ascending (reference pixel, emission slot) -- a key that does not depend on
+    // the arrival order of the bucket pass.  (key, CSR index) pairs are sorted per wave in LDS.
+    int *keys = s_sort + wave * 2 * max_sort;
+    int *vals = keys + max_sort;
+    const bool sorted = cnt <= max_sort;
+    if (sorted) {
+        int npow = 1;
+        while (npow < cnt) npow <<= 1;
+        for (int i = lane; i < npow; i += kWave) {
+            keys[i] = (i < cnt) ? csr_p[seg + i] : 0x7fffffff;
+            vals[i] = i;
+        }
+        __builtin_amdgcn_wave_barrier();
+        for (int k = 2; k <= npow; k <<= 1)
+            for (int j = k >> 1; j > 0; j >>= 1) {
+                for (int i = lane; i < npow; i += kWave) {
+                    const int l = i ^ j;
+                    if (l > i) {
+                        const int a = keys[i], b = keys[l];
+                        const bool up = (i & k) == 0;
+                        if ((a > b) == up) {
+                            keys[i] = b;
+                            keys[l] = a;
+                            const int va = vals[i];
+                            vals[i] = vals[l];
+                            vals[l] = va;
+                        }
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+    }
+    const float4 *G4 = reinterpret_cast<const float4 *>(gout) + (size_t)n * HW * nvec;
+    const float4 *F4 = reinterpret_cast<const float4 *>(fref) + (size_t)n * HW * nvec;
+    for (int e0 = 0; e0 < cnt; e0 += kWave) {
+        const int m = min(kWave, cnt - e0);
+        int idx = 0, pp = 0;
+        float aa = 0.f, bb = 0.f;
+        if (lane < m) {
+            idx = sorted ? vals[e0 + lane] : (e0 + lane);
+            pp = csr_p[seg + idx] / cap;
+            aa = csr_a[seg + idx];
+            bb = csr_b[seg + idx];
+        }
+        for (int j = 0; j < m; ++j) {
+            const int pj = __builtin_amdgcn_readlane(pp, j);
+            const float aj = lane_bcast(aa, j), bj = lane_bcast(bb, j);
+#pragma unroll
+            for (int c = 0; c < CPL; ++c) {
+                if (mask & 2) acc[c] = f4_fma(aj, G4[(size_t)pj * nvec + voff[c]], acc[c]);
+                if (mask & 1) acc[c] = f4_fma(bj, F4[(size_t)pj * nvec + voff[c]], acc[c]);
+            }
+        }
+    }
+    float4 *o4 = reinterpret_cast<float4 *>(gsrc) + (size_t)gu * nvec;
+#pragma unroll
+    for (int c = 0; c < CPL; ++c) {
+        const int v = lane + c * kWave;
+        if (v < nvec) o4[v] = acc[c];
     }
 }
 
@@ -1208,10 +1409,15 @@ void launch_fwd(const FwdParams &p, int variant, dim3 grid, size_t lds, hipStrea
 template <int CPD, int KPL>
 void launch_bwd(const BwdParams &p, int variant, dim3 grid, hipStream_t st)
 {
-    if (variant & ET_VARIANT_SAFE_REDUCE)
-        hipLaunchKernelGGL((epipolar_bwd_kernel<CPD, KPL, false>), grid, dim3(256), 0, st, p);
-    else
-        hipLaunchKernelGGL((epipolar_bwd_kernel<CPD, KPL, true>), grid, dim3(256), 0, st, p);
+    const bool emit = p.ent_u != nullptr;
+    const size_t lds = emit ? (size_t)kWavesPerBlock * 3 * p.cap * sizeof(float) : 0;
+    if (variant & ET_VARIANT_SAFE_REDUCE) {
+        if (emit) hipLaunchKernelGGL((epipolar_bwd_kernel<CPD, KPL, false, true>), grid, dim3(256), lds, st, p);
+        else hipLaunchKernelGGL((epipolar_bwd_kernel<CPD, KPL, false, false>), grid, dim3(256), lds, st, p);
+    } else {
+        if (emit) hipLaunchKernelGGL((epipolar_bwd_kernel<CPD, KPL, true, true>), grid, dim3(256), lds, st, p);
+        else hipLaunchKernelGGL((epipolar_bwd_kernel<CPD, KPL, true, false>), grid, dim3(256), lds, st, p);
+    }
 }
 
 }  // namespace
@@ -1304,19 +1510,34 @@ int et_epipolar_forward(const EtLayerDesc *desc, const float *xs, const float *y
     return check_launch("et_epipolar_forward");
 }
 
+size_t et_epipolar_backward_workspace_bytes(const EtLayerDesc *desc)
+{
+    if (validate(desc)) return 0;
+    const size_t rows = (size_t)desc->N * desc->H * desc->W;
+    const size_t cap = 4u * (size_t)desc->K;
+    return rows * cap * 4u * 6u + rows * 4u * 4u + 256u;
+}
+
 int et_epipolar_backward(const EtLayerDesc *desc, const float *xs, const float *ys, const float *steps,
                          const float *cam, const float *feat_ref, const float *feat_src,
-                         const float *grad_out, float *grad_ref, float *grad_src, void *stream)
+                         const float *grad_out, float *grad_ref, float *grad_src, void *workspace,
+                         size_t workspace_bytes, void *stream)
 {
     if (int e = validate(desc)) return e;
     if (!xs || !ys || !steps || !cam || !feat_ref || !feat_src || !grad_out || !grad_ref || !grad_src)
         return fail("et_epipolar_backward: NULL pointer");
     hipStream_t st = (hipStream_t)stream;
     const int HW = desc->H * desc->W;
-    const size_t bytes = (size_t)desc->N * HW * desc->C * sizeof(float);
-    hipError_t me = hipMemsetAsync(grad_src, 0, bytes, st);
-    if (me != hipSuccess) return fail("hipMemsetAsync(grad_src): %s", hipGetErrorString(me));
+    const size_t rows = (size_t)desc->N * HW;
+    const size_t bytes = rows * desc->C * sizeof(float);
+    const bool gather = workspace != nullptr && !(desc->variant & ET_VARIANT_BWD_ATOMIC) && desc->src_grad_mask != 0;
+    if (gather && workspace_bytes < et_epipolar_backward_workspace_bytes(desc))
+        return fail("et_epipolar_backward: workspace of %zu bytes is smaller than the %zu required", workspace_bytes,
+                    et_epipolar_backward_workspace_bytes(desc));
+    if (gather && ((long long)HW * 4 * desc->K >= (1LL << 31)))
+        return fail("et_epipolar_backward: H*W*4K must stay below 2^31 for the gather-form backward");
     BwdParams p;
+    std::memset(&p, 0, sizeof(p));
     p.d = *desc;
     p.xs = xs; p.ys = ys; p.steps = steps; p.cam = cam;
     p.fref = feat_ref; p.fsrc = feat_src; p.gout = grad_out;
@@ -1325,6 +1546,29 @@ int et_epipolar_backward(const EtLayerDesc *desc, const float *xs, const float *
     const long long total = (long long)p.blocks_per_pair * desc->N;
     if (total > 0x7fffffffLL) return fail("grid too large");
     p.total_blocks = (int)total;
+    int *row_base = nullptr, *row_cursor = nullptr, *csr_p = nullptr;
+    float *csr_a = nullptr, *csr_b = nullptr;
+    if (gather) {
+        // carve the workspace: 3 pixel-major entry arrays, 3 row-major (CSR) arrays, 4 per-row int arrays
+        p.cap = 4 * desc->K;
+        const size_t slots = rows * p.cap;
+        char *w = reinterpret_cast<char *>((reinterpret_cast<uintptr_t>(workspace) + 255) & ~(uintptr_t)255);
+        p.ent_u = reinterpret_cast<int *>(w);        w += slots * 4;
+        p.ent_a = reinterpret_cast<float *>(w);      w += slots * 4;
+        p.ent_b = reinterpret_cast<float *>(w);      w += slots * 4;
+        csr_p = reinterpret_cast<int *>(w);          w += slots * 4;
+        csr_a = reinterpret_cast<float *>(w);        w += slots * 4;
+        csr_b = reinterpret_cast<float *>(w);        w += slots * 4;
+        p.ent_count = reinterpret_cast<int *>(w);    w += rows * 4;
+        p.row_count = reinterpret_cast<int *>(w);    w += rows * 4;
+        row_base = reinterpret_cast<int *>(w);       w += rows * 4;
+        row_cursor = reinterpret_cast<int *>(w);
+        hipError_t me = hipMemsetAsync(p.row_count, 0, rows * 4, st);
+        if (me != hipSuccess) return fail("hipMemsetAsync(row_count): %s", hipGetErrorString(me));
+    } else {
+        hipError_t me = hipMemsetAsync(grad_src, 0, bytes, st);
+        if (me != hipSuccess) return fail("hipMemsetAsync(grad_src): %s", hipGetErrorString(me));
+    }
     const dim3 grid((unsigned)total);
     const int cpd = (desc->C + 63) / 64, kpl = (desc->K + 63) / 64;
     const int v = desc->variant;
@@ -1337,7 +1581,27 @@ int et_epipolar_backward(const EtLayerDesc *desc, const float *xs, const float *
     else if (cpd <= 4) { ET_BWD_CASE(4) }
     else { ET_BWD_CASE(8) }
 #undef ET_BWD_CASE
-    return check_launch("et_epipolar_backward");
+    if (int e = check_launch("et_epipolar_backward")) return e;
+    if (gather) {
+        hipLaunchKernelGGL(bwd_scan_kernel, dim3(desc->N), dim3(256), 0, st, HW, p.row_count, row_base, row_cursor);
+        const size_t slots = rows * p.cap;
+        const unsigned bblocks = (unsigned)((slots + 255) / 256 < 65536 ? (slots + 255) / 256 : 65536);
+        hipLaunchKernelGGL(bwd_bucket_kernel, dim3(bblocks), dim3(256), 0, st, HW, p.cap, slots, p.ent_count, p.ent_u,
+                           p.ent_a, p.ent_b, row_base, row_cursor, csr_p, csr_a, csr_b);
+        const int max_sort = 1024;  // entries per source pixel ordered in LDS (beyond that: arrival order)
+        const unsigned gblocks = (unsigned)((rows + kWavesPerBlock - 1) / kWavesPerBlock);
+        const size_t lds = (size_t)kWavesPerBlock * 2 * max_sort * sizeof(int);
+        if (desc->C <= 256)
+            hipLaunchKernelGGL((epipolar_bwd_gather_kernel<1>), dim3(gblocks), dim3(256), lds, st, HW, desc->C, p.cap,
+                               (int)rows, desc->src_grad_mask, p.row_count, row_base, csr_p, csr_a, csr_b, feat_ref,
+                               grad_out, grad_src, max_sort);
+        else
+            hipLaunchKernelGGL((epipolar_bwd_gather_kernel<2>), dim3(gblocks), dim3(256), lds, st, HW, desc->C, p.cap,
+                               (int)rows, desc->src_grad_mask, p.row_count, row_base, csr_p, csr_a, csr_b, feat_ref,
+                               grad_out, grad_src, max_sort);
+        if (int e = check_launch("et_epipolar_backward(gather)")) return e;
+    }
+    return 0;
 }
 
 int et_residual_epilogue(int64_t num_pixels, int32_t C, const float *feat, const float *out, const float *y,

@@ -151,17 +151,36 @@ def forward_nhwc(spec: LayerSpec, ref: torch.Tensor, src: torch.Tensor, cam: tor
     return out, attn, corr
 
 
-def backward_nhwc(spec: LayerSpec, ref, src, cam, grad_out):
+_workspaces = {}
+
+
+def _workspace(device, nbytes: int) -> torch.Tensor:
+    """Scratch for the gather-form backward, grown on demand and kept per device (288 GB of HBM: a few GB
+    of scratch is cheap; all use is stream-ordered on the caller's stream)."""
+    key = str(device)
+    buf = _workspaces.get(key)
+    if buf is None or buf.numel() < nbytes:
+        _workspaces[key] = buf = torch.empty(nbytes, dtype=torch.uint8, device=device)
+    return buf
+
+
+def backward_nhwc(spec: LayerSpec, ref, src, cam, grad_out, use_workspace=True):
     n, h, w, c = ref.shape
     xs, ys, steps = spec.constants(ref.device)
     grad_out = grad_out.contiguous()
     g_ref = torch.empty_like(ref)
     g_src = torch.empty_like(src)
     d = spec.desc(n, c)
+    lib = _lib.load()
+    ws, ws_bytes = None, 0
+    if use_workspace:
+        ws_bytes = int(lib.et_epipolar_backward_workspace_bytes(ctypes.byref(d)))
+        ws = _workspace(ref.device, ws_bytes)
     with torch.cuda.device(ref.device):
-        _lib.check(_lib.load().et_epipolar_backward(ctypes.byref(d), _ptr(xs), _ptr(ys), _ptr(steps), _ptr(cam),
-                                                    _ptr(ref), _ptr(src), _ptr(grad_out), _ptr(g_ref), _ptr(g_src),
-                                                    _stream(ref)), "et_epipolar_backward")
+        _lib.check(lib.et_epipolar_backward(ctypes.byref(d), _ptr(xs), _ptr(ys), _ptr(steps), _ptr(cam),
+                                            _ptr(ref), _ptr(src), _ptr(grad_out), _ptr(g_ref), _ptr(g_src),
+                                            _ptr(ws), ctypes.c_size_t(ws_bytes), _stream(ref)),
+                   "et_epipolar_backward")
     return g_ref, g_src
 
 

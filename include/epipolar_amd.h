@@ -22,13 +22,14 @@
 #ifndef EPIPOLAR_AMD_H_
 #define EPIPOLAR_AMD_H_
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
 extern "C" {
 #endif
 
-#define ET_ABI_VERSION 2
+#define ET_ABI_VERSION 3
 
 /* Static description of one layer call: the cfg keys the reference reads in
  * Epipolar.__init__ (epipolar.py:12-54) and at call time (epipolar.py:303-311,
@@ -73,6 +74,7 @@ typedef struct EtLayerDesc {
 #define ET_VARIANT_PIPELINE 512    /* multi kernels: request step k+1's rows right after step k is interpolated */
 #define ET_VARIANT_MULTI2 1024     /* C == 256: two pixels per wave in lockstep (32 lanes x 8 channels each) */
 #define ET_VARIANT_MULTI4 2048     /* C == 256: four pixels per wave in lockstep (16 lanes x 16 channels)    */
+#define ET_VARIANT_BWD_ATOMIC 4096 /* backward: float-atomic scatter even when a workspace is given      */
 #define ET_VARIANT_BASELINE 256    /* batches of 8, compiler-chosen registers, pixels 4w..4w+3 per wave   */
 #define ET_VARIANT_ABLATE_NO_LOADS 64  /* profiling only, WRONG RESULTS: no tap loads after the first sample */
 #define ET_VARIANT_ABLATE_ONE_ROW 128  /* profiling only, WRONG RESULTS: every tap load reads source row 0    */
@@ -110,11 +112,19 @@ int et_epipolar_forward(const EtLayerDesc *desc, const float *xs, const float *y
  * inputs; nothing saved by the forward is needed.
  *   grad_out  : (N,H,W,C)
  *   grad_ref  : (N,H,W,C) written
- *   grad_src  : (N,H,W,C) zero-filled by this call on `stream`, then
- *               accumulated with float atomics (bilinear-transpose scatter) */
+ *   grad_src  : (N,H,W,C) written
+ *   workspace : device scratch of at least et_epipolar_backward_workspace_bytes(desc)
+ *               bytes, or NULL.  With a workspace d(feat_src) is computed in gather
+ *               form (per-(pixel,row) coefficients -> counting sort by source row ->
+ *               one wave per source pixel sums alpha*g_p + beta*f_p in ascending p):
+ *               no float atomics, bit-reproducible.  With NULL (or variant bit
+ *               ET_VARIANT_BWD_ATOMIC) grad_src is zero-filled and accumulated with
+ *               float atomics (bilinear-transpose scatter, run-to-run rounding noise). */
+size_t et_epipolar_backward_workspace_bytes(const EtLayerDesc *desc);
 int et_epipolar_backward(const EtLayerDesc *desc, const float *xs, const float *ys, const float *steps,
                          const float *cam, const float *feat_ref, const float *feat_src,
-                         const float *grad_out, float *grad_ref, float *grad_src, void *stream);
+                         const float *grad_out, float *grad_ref, float *grad_src, void *workspace,
+                         size_t workspace_bytes, void *stream);
 
 /* Residual fusion epilogue: x = feat + out + (y * scale[c] + shift[c])
  *   (epipolar.py:250-253 with ZRESIDUAL, then resnet.py:388 `ret + feat`),

@@ -24,7 +24,7 @@ def lib():
 
 def test_header_symbols_are_exported(lib):
     text = open(os.path.join(ROOT, "include", "epipolar_amd.h")).read()
-    declared = set(re.findall(r"^(?:int|const char \*)\s*(et_\w+)\(", text, flags=re.M))
+    declared = set(re.findall(r"^(?:int|size_t|const char \*)\s*(et_\w+)\(", text, flags=re.M))
     assert declared, "no declarations parsed"
     assert declared == set(_lib.exported_symbols())
     for name in declared:

@@ -100,15 +100,20 @@ def test_zero_feature_pixel_uniform_attention(env, case):
     assert np.allclose(attn[0, :, 3, 5], 1.0 / d["dims"]["K"], atol=1e-7)       # epipolar.py:298 (H3)
 
 
+@pytest.mark.parametrize("gather", [True, False])
 @pytest.mark.parametrize("variant", [0, 1])
 @pytest.mark.parametrize("case", golden_cases())
-def test_backward_vs_reference_autograd(env, case, variant):
+def test_backward_vs_reference_autograd(env, case, variant, gather):
+    """gather=True: atomic-free gather-form d(feat_src) (workspace); False: float-atomic scatter."""
     _lib, camera, ops = env
     d = load_golden(case)
     spec, cam, ref, src, _, _, _ = _run_forward(env, d, variant)
     g = ops.to_nhwc(_dev(d["grad_out"]))
-    g_ref, g_src = ops.backward_nhwc(spec, ref, src, cam, g)
+    g_ref, g_src = ops.backward_nhwc(spec, ref, src, cam, g, use_workspace=gather)
     torch.cuda.synchronize()
+    if gather:      # no float atomics: bit-reproducible
+        g_ref2, g_src2 = ops.backward_nhwc(spec, ref, src, cam, g, use_workspace=True)
+        assert torch.equal(g_src, g_src2) and torch.equal(g_ref, g_ref2)
     for got, want in ((g_ref, d["grad_feat1"]), (g_src, d["grad_feat2"])):
         got = got.permute(0, 3, 1, 2).cpu().numpy()
         scale = np.abs(want).max()
@@ -254,11 +259,12 @@ def test_full_shape_pairs_vs_oracle(env, oracle_mod, shape, variant):
     g1, g2 = oracle_mod.backward(oracle_mod.LayerSpec(H, H, K), f1[:1].numpy(), f2[:1].numpy(),
                                  want["sample_locs"][:, :1], g.numpy())
     spec1 = ops.LayerSpec(H=H, W=H, K=K)
-    gr, gs = ops.backward_nhwc(spec1, ref[:1].contiguous(), src[:1].contiguous(), cam[:1].contiguous(),
-                               ops.to_nhwc(g.cuda()))
-    for got, wantg in ((gr, g1), (gs, g2)):
-        scale = np.abs(wantg).max()
-        assert np.abs(got.permute(0, 3, 1, 2).cpu().numpy() - wantg).max() <= TOL_GRAD_REL * scale
+    for use_ws in (True, False):
+        gr, gs = ops.backward_nhwc(spec1, ref[:1].contiguous(), src[:1].contiguous(), cam[:1].contiguous(),
+                                   ops.to_nhwc(g.cuda()), use_workspace=use_ws)
+        for got, wantg in ((gr, g1), (gs, g2)):
+            scale = np.abs(wantg).max()
+            assert np.abs(got.permute(0, 3, 1, 2).cpu().numpy() - wantg).max() <= TOL_GRAD_REL * scale
 
 
 def test_config2_full_batch_properties(env):
