@@ -1143,6 +1143,229 @@ __global__ __launch_bounds__(kWave *kWavesPerBlock) void epipolar_bwd_kernel(con
 }
 
 // ----------------------------------------------------------------------------
+// backward, emit form with the forward's channel mapping (float4 per lane):
+// d(feat_ref) + per-(pixel, source row) coefficients for the gather pass
+// ----------------------------------------------------------------------------
+template <int CPL, int KPL, bool FAST>
+__global__ __launch_bounds__(kWave *kWavesPerBlock) void epipolar_bwd_emit_kernel(const BwdParams p)
+{
+    extern __shared__ float s_dyn[];  // per wave: [KPL*64] float4 weights, then [cap] u, [cap] alpha, [cap] beta
+    const EtLayerDesc &d = p.d;
+    const int H = d.H, W = d.W, C = d.C, K = d.K;
+    const int HW = H * W;
+    const int nvec = C >> 2;
+
+    const int vb = xcd_remap(blockIdx.x, p.total_blocks);
+    const int n = vb / p.blocks_per_pair;
+    const int pb = vb - n * p.blocks_per_pair;
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int pix_base = pb * kPixPerBlock;
+    char *wbase = reinterpret_cast<char *>(s_dyn) + (size_t)wave * (KPL * kWave * 16 + 3 * p.cap * 4);
+    float4 *s_wt = reinterpret_cast<float4 *>(wbase);
+    int *s_eu = reinterpret_cast<int *>(wbase + KPL * kWave * 16);
+    float *s_ea = reinterpret_cast<float *>(s_eu) + p.cap;
+    float *s_eb = s_ea + p.cap;
+
+    const float *cam = p.cam + (size_t)n * ET_CAM_STRIDE;
+    const __amdgpu_buffer_rsrc_t src = make_rsrc(p.fsrc + (size_t)n * HW * C, (unsigned)HW * C * 4u);
+    const int row_bytes = C * 4;
+    const float neg_inf = -__builtin_huge_valf();
+    int voff[CPL];
+#pragma unroll
+    for (int c = 0; c < CPL; ++c) voff[c] = min(lane + c * kWave, nvec - 1) * 16;
+
+    for (int pp = 0; pp < kPixPerWave; ++pp) {
+        const int pix = pix_base + pp * kWavesPerBlock + wave;  // waves of a block on neighbouring pixels
+        if (pix >= HW) continue;
+        const int h = pix / W, w = pix - h * W;
+        const et::Segment seg = et::epipolar_segment(d, cam, p.xs[w], p.ys[h]);
+        SampleTable<KPL> tb;
+        build_sample_table<KPL, true>(d, seg, p.steps, lane, row_bytes, tb);
+        float v_logit[KPL], v_da[KPL];
+        bool v_masked[KPL];
+#pragma unroll
+        for (int s = 0; s < KPL; ++s) {
+            v_logit[s] = neg_inf;
+            v_da[s] = 0.f;
+            v_masked[s] = false;
+            s_wt[s * kWave + lane] = make_float4(tb.w[s][0], tb.w[s][1], tb.w[s][2], tb.w[s][3]);
+        }
+        __builtin_amdgcn_wave_barrier();
+
+        float4 f1[CPL], g[CPL], R[4][CPL];
+        const float4 *ref = reinterpret_cast<const float4 *>(p.fref + ((size_t)n * HW + pix) * C);
+        const float4 *go = reinterpret_cast<const float4 *>(p.gout + ((size_t)n * HW + pix) * C);
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) {
+            const int v = lane + c * kWave;
+            f1[c] = (v < nvec) ? ref[v] : f4_zero();
+            g[c] = (v < nvec) ? go[v] : f4_zero();
+#pragma unroll
+            for (int r = 0; r < 4; ++r) R[r][c] = f4_zero();
+        }
+
+        // ---------------- pass A: logits and da -----------------------------------
+#pragma unroll
+        for (int s = 0; s < KPL; ++s) {
+            const int kcount = min(kWave, K - s * kWave);
+            for (int kb = 0; kb < kcount; kb += 8) {
+                float p1[8], p2[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int kk = kb + j;
+                    p1[j] = 0.f;
+                    p2[j] = 0.f;
+                    if (kk < kcount) {
+                        const int need = __builtin_amdgcn_readlane(tb.need[s], kk);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            if (need & (1 << r)) {
+                                const int off = __builtin_amdgcn_readlane(tb.off[s][r], kk);
+#pragma unroll
+                                for (int c = 0; c < CPL; ++c) R[r][c] = buf_load_f4(src, voff[c], off);
+                            }
+                        }
+                        const float4 wv = s_wt[s * kWave + kk];
+#pragma unroll
+                        for (int c = 0; c < CPL; ++c) {
+                            float4 sv = f4_mul(wv.x, R[0][c]);
+                            sv = f4_fma(wv.y, R[1][c], sv);
+                            sv = f4_fma(wv.z, R[2][c], sv);
+                            sv = f4_fma(wv.w, R[3][c], sv);
+                            p1[j] += f4_dot(sv, f1[c]);
+                            p2[j] += f4_dot(sv, g[c]);
+                        }
+                    }
+                }
+                const float u1 = reduce8<FAST>(p1, lane);
+                const float u2 = reduce8<FAST>(p2, lane);
+                const bool masked = (u1 == 0.f);
+                float sv = masked ? -1e10f : u1;
+                sv = d.softmax_enabled ? sv * d.softmax_scale : sv / (float)K;
+                const int srcl = lane_of_sample<8>(lane & 7);
+                const float mine_l = __shfl(sv, srcl);
+                const float mine_d = __shfl(u2, srcl);
+                const int mine_m = __shfl((int)masked, srcl);
+                if ((lane >> 3) == (kb >> 3)) {
+                    v_logit[s] = mine_l;
+                    v_da[s] = mine_d;
+                    v_masked[s] = mine_m != 0;
+                }
+            }
+        }
+
+        // ---------------- soft-max gradient, lanes <-> samples -----------------------
+        float v_a[KPL], v_ds[KPL];
+        if (d.softmax_enabled) {
+            float mx = neg_inf;
+#pragma unroll
+            for (int s = 0; s < KPL; ++s) mx = fmaxf(mx, (s * kWave + lane < K) ? v_logit[s] : neg_inf);
+            mx = wave_max(mx);
+            float lsum = 0.f;
+#pragma unroll
+            for (int s = 0; s < KPL; ++s) {
+                v_a[s] = (s * kWave + lane < K) ? expf(v_logit[s] - mx) : 0.f;
+                lsum += v_a[s];
+            }
+            const float denom = wave_sum(lsum);
+            float dsum = 0.f;
+#pragma unroll
+            for (int s = 0; s < KPL; ++s) {
+                v_a[s] = v_a[s] / denom;
+                dsum = fmaf(v_a[s], v_da[s], dsum);
+            }
+            const float dot = wave_sum(dsum);
+#pragma unroll
+            for (int s = 0; s < KPL; ++s)
+                v_ds[s] = v_masked[s] ? 0.f : d.softmax_scale * v_a[s] * (v_da[s] - dot);
+        } else {
+#pragma unroll
+            for (int s = 0; s < KPL; ++s) {
+                const bool in = s * kWave + lane < K;
+                v_a[s] = in ? v_logit[s] : 0.f;
+                v_ds[s] = (in && !v_masked[s]) ? v_da[s] / (float)K : 0.f;
+            }
+        }
+        // ---------------- pass B: d(feat_ref) and the coefficient entries ----------------
+        float4 d1[CPL];
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) {
+            d1[c] = f4_zero();
+#pragma unroll
+            for (int r = 0; r < 4; ++r) R[r][c] = f4_zero();
+        }
+        int tag[4] = {-1, -1, -1, -1};
+        float ea[4] = {0.f, 0.f, 0.f, 0.f}, eb[4] = {0.f, 0.f, 0.f, 0.f};
+        int ecount = 0;
+        auto emit = [&](int r) {  // wave-uniform call
+            if (lane == 0) {
+                s_eu[ecount] = tag[r] / row_bytes;
+                s_ea[ecount] = ea[r];
+                s_eb[ecount] = eb[r];
+            }
+            ++ecount;
+            ea[r] = 0.f;
+            eb[r] = 0.f;
+        };
+#pragma unroll
+        for (int s = 0; s < KPL; ++s) {
+            const int kcount = min(kWave, K - s * kWave);
+            for (int kk = 0; kk < kcount; ++kk) {
+                const int need = __builtin_amdgcn_readlane(tb.need[s], kk);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    if (need & (1 << r)) {
+                        const int off = __builtin_amdgcn_readlane(tb.off[s][r], kk);
+                        if (tag[r] >= 0) emit(r);
+#pragma unroll
+                        for (int c = 0; c < CPL; ++c) R[r][c] = buf_load_f4(src, voff[c], off);
+                        tag[r] = off;
+                    }
+                }
+                const float4 wv = s_wt[s * kWave + kk];
+                const float ak = lane_bcast(v_a[s], kk), dsk = lane_bcast(v_ds[s], kk);
+                // OTHER_GRAD (epipolar.py:141-153): which of the two uses of feat_src carry gradient
+                const float ak_src = (d.src_grad_mask & 2) ? ak : 0.f;
+                const float dsk_src = (d.src_grad_mask & 1) ? dsk : 0.f;
+                ea[0] = fmaf(wv.x, ak_src, ea[0]); eb[0] = fmaf(wv.x, dsk_src, eb[0]);
+                ea[1] = fmaf(wv.y, ak_src, ea[1]); eb[1] = fmaf(wv.y, dsk_src, eb[1]);
+                ea[2] = fmaf(wv.z, ak_src, ea[2]); eb[2] = fmaf(wv.z, dsk_src, eb[2]);
+                ea[3] = fmaf(wv.w, ak_src, ea[3]); eb[3] = fmaf(wv.w, dsk_src, eb[3]);
+#pragma unroll
+                for (int c = 0; c < CPL; ++c) {
+                    float4 sv = f4_mul(wv.x, R[0][c]);
+                    sv = f4_fma(wv.y, R[1][c], sv);
+                    sv = f4_fma(wv.z, R[2][c], sv);
+                    sv = f4_fma(wv.w, R[3][c], sv);
+                    d1[c] = f4_fma(dsk, sv, d1[c]);
+                }
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (tag[r] >= 0) emit(r);
+        __builtin_amdgcn_wave_barrier();
+        const size_t ebase = ((size_t)n * HW + pix) * p.cap;
+        for (int i = lane; i < ecount; i += kWave) {
+            const int u = s_eu[i];
+            p.ent_u[ebase + i] = u;
+            p.ent_a[ebase + i] = s_ea[i];
+            p.ent_b[ebase + i] = s_eb[i];
+            atomicAdd(&p.row_count[(size_t)n * HW + u], 1);
+        }
+        if (lane == 0) p.ent_count[(size_t)n * HW + pix] = ecount;
+        float4 *gr = reinterpret_cast<float4 *>(p.gref + ((size_t)n * HW + pix) * C);
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) {
+            const int v = lane + c * kWave;
+            if (v < nvec) gr[v] = d1[c];
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// ----------------------------------------------------------------------------
 // gather-form backward of d(feat_src): scan, bucket, gather
 // ----------------------------------------------------------------------------
 // Per pair: exclusive prefix sum of row_count[HW] -> row_base[HW] (one block per pair).
@@ -1176,25 +1399,30 @@ __global__ __launch_bounds__(256) void bwd_scan_kernel(int HW, const int *row_co
     }
 }
 
-// One thread per entry slot of the pixel-major buffer: move it to its source row's segment.
-__global__ __launch_bounds__(256) void bwd_bucket_kernel(int HW, int cap, size_t total_slots, const int *ent_count,
+// One wave per reference pixel: move its entries to their source rows' segments.
+__global__ __launch_bounds__(256) void bwd_bucket_kernel(int HW, int cap, int total_rows, const int *ent_count,
                                                           const int *ent_u, const float *ent_a, const float *ent_b,
                                                           const int *row_base, int *row_cursor, int *csr_p,
                                                           float *csr_a, float *csr_b)
 {
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total_slots; i += (size_t)gridDim.x * blockDim.x) {
-        const size_t gp = i / cap;  // global reference pixel n*HW + p
-        const int slot = (int)(i - gp * cap);
-        if (slot >= ent_count[gp]) continue;
-        const size_t n = gp / HW;
-        const int pidx = (int)(gp - n * HW);
-        const int u = ent_u[i];
-        const size_t gu = n * HW + u;
-        const int pos = row_base[gu] + atomicAdd(&row_cursor[gu], 1);
-        const size_t o = n * (size_t)HW * cap + pos;  // per-pair CSR region of HW*cap slots
-        csr_p[o] = pidx * cap + slot;                 // unique, run-independent ordering key
-        csr_a[o] = ent_a[i];
-        csr_b[o] = ent_b[i];
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave_global = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    const int nwaves = gridDim.x * kWavesPerBlock;
+    for (int gp = wave_global; gp < total_rows; gp += nwaves) {  // global reference pixel n*HW + p
+        const int cnt = ent_count[gp];
+        const int n = gp / HW;
+        const int pidx = gp - n * HW;
+        const size_t ebase = (size_t)gp * cap;
+        const size_t pair_rows = (size_t)n * HW;
+        for (int slot = lane; slot < cnt; slot += kWave) {
+            const int u = ent_u[ebase + slot];
+            const size_t gu = pair_rows + u;
+            const int pos = row_base[gu] + atomicAdd(&row_cursor[gu], 1);
+            const size_t o = pair_rows * cap + pos;     // per-pair CSR region of HW*cap slots
+            csr_p[o] = pidx * cap + slot;               // unique, run-independent ordering key
+            csr_a[o] = ent_a[ebase + slot];
+            csr_b[o] = ent_b[ebase + slot];
+        }
     }
 }
 
@@ -1256,8 +1484,9 @@ __global__ __launch_bounds__(256) void epipolar_bwd_gather_kernel(int HW, int C,
                 __builtin_amdgcn_wave_barrier();
             }
     }
-    const float4 *G4 = reinterpret_cast<const float4 *>(gout) + (size_t)n * HW * nvec;
-    const float4 *F4 = reinterpret_cast<const float4 *>(fref) + (size_t)n * HW * nvec;
+    const __amdgpu_buffer_rsrc_t G4 = make_rsrc(gout + (size_t)n * HW * C, (unsigned)HW * C * 4u);
+    const __amdgpu_buffer_rsrc_t F4 = make_rsrc(fref + (size_t)n * HW * C, (unsigned)HW * C * 4u);
+    const int row_bytes = C * 4;
     for (int e0 = 0; e0 < cnt; e0 += kWave) {
         const int m = min(kWave, cnt - e0);
         int idx = 0, pp = 0;
@@ -1269,12 +1498,12 @@ __global__ __launch_bounds__(256) void epipolar_bwd_gather_kernel(int HW, int C,
             bb = csr_b[seg + idx];
         }
         for (int j = 0; j < m; ++j) {
-            const int pj = __builtin_amdgcn_readlane(pp, j);
+            const int pj = __builtin_amdgcn_readlane(pp, j) * row_bytes;  // scalar row offset
             const float aj = lane_bcast(aa, j), bj = lane_bcast(bb, j);
 #pragma unroll
             for (int c = 0; c < CPL; ++c) {
-                if (mask & 2) acc[c] = f4_fma(aj, G4[(size_t)pj * nvec + voff[c]], acc[c]);
-                if (mask & 1) acc[c] = f4_fma(bj, F4[(size_t)pj * nvec + voff[c]], acc[c]);
+                if (mask & 2) acc[c] = f4_fma(aj, buf_load_f4(G4, voff[c] * 16, pj), acc[c]);
+                if (mask & 1) acc[c] = f4_fma(bj, buf_load_f4(F4, voff[c] * 16, pj), acc[c]);
             }
         }
     }
@@ -1572,6 +1801,18 @@ int et_epipolar_backward(const EtLayerDesc *desc, const float *xs, const float *
     const dim3 grid((unsigned)total);
     const int cpd = (desc->C + 63) / 64, kpl = (desc->K + 63) / 64;
     const int v = desc->variant;
+    if (gather) {
+        const size_t lds_e = (size_t)kWavesPerBlock * (kpl * kWave * 16 + 3 * p.cap * 4);
+        const bool safe = v & ET_VARIANT_SAFE_REDUCE;
+#define ET_EMIT(CPLv, KPLv)                                                                                        \
+    do {                                                                                                           \
+        if (safe) hipLaunchKernelGGL((epipolar_bwd_emit_kernel<CPLv, KPLv, false>), grid, dim3(256), lds_e, st, p); \
+        else hipLaunchKernelGGL((epipolar_bwd_emit_kernel<CPLv, KPLv, true>), grid, dim3(256), lds_e, st, p);       \
+    } while (0)
+        if (desc->C <= 256) { if (kpl == 1) ET_EMIT(1, 1); else if (kpl == 2) ET_EMIT(1, 2); else ET_EMIT(1, 4); }
+        else { if (kpl == 1) ET_EMIT(2, 1); else if (kpl == 2) ET_EMIT(2, 2); else ET_EMIT(2, 4); }
+#undef ET_EMIT
+    } else {
 #define ET_BWD_CASE(CPD)                                   \
     if (kpl == 1) launch_bwd<CPD, 1>(p, v, grid, st);      \
     else if (kpl == 2) launch_bwd<CPD, 2>(p, v, grid, st); \
@@ -1581,13 +1822,14 @@ int et_epipolar_backward(const EtLayerDesc *desc, const float *xs, const float *
     else if (cpd <= 4) { ET_BWD_CASE(4) }
     else { ET_BWD_CASE(8) }
 #undef ET_BWD_CASE
+    }
     if (int e = check_launch("et_epipolar_backward")) return e;
     if (gather) {
         hipLaunchKernelGGL(bwd_scan_kernel, dim3(desc->N), dim3(256), 0, st, HW, p.row_count, row_base, row_cursor);
-        const size_t slots = rows * p.cap;
-        const unsigned bblocks = (unsigned)((slots + 255) / 256 < 65536 ? (slots + 255) / 256 : 65536);
-        hipLaunchKernelGGL(bwd_bucket_kernel, dim3(bblocks), dim3(256), 0, st, HW, p.cap, slots, p.ent_count, p.ent_u,
-                           p.ent_a, p.ent_b, row_base, row_cursor, csr_p, csr_a, csr_b);
+        const unsigned bblocks = (unsigned)((rows + kWavesPerBlock - 1) / kWavesPerBlock < 16384
+                                            ? (rows + kWavesPerBlock - 1) / kWavesPerBlock : 16384);
+        hipLaunchKernelGGL(bwd_bucket_kernel, dim3(bblocks), dim3(256), 0, st, HW, p.cap, (int)rows, p.ent_count,
+                           p.ent_u, p.ent_a, p.ent_b, row_base, row_cursor, csr_p, csr_a, csr_b);
         const int max_sort = 1024;  // entries per source pixel ordered in LDS (beyond that: arrival order)
         const unsigned gblocks = (unsigned)((rows + kWavesPerBlock - 1) / kWavesPerBlock);
         const size_t lds = (size_t)kWavesPerBlock * 2 * max_sort * sizeof(int);
