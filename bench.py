@@ -58,6 +58,22 @@ def parse():
     return ap.parse_args()
 
 
+def measured_hbm_traffic(C, H, W, K, n_pairs):
+    """HBM bytes per launch of the fused forward kernel from the committed rocprofv3 PMC pass
+    (profiles/fwd_pmc_latest.json, written by scripts/gpu_pmc.sh): (2 * FETCH_SIZE + WRITE_SIZE) KiB --
+    FETCH_SIZE counts half of a 16-B/lane coalesced stream on gfx950 (MI355X_MICROARCH.md, HBM).
+    None when no measurement of this exact workload is committed."""
+    path = os.path.join(ROOT, "profiles", "fwd_pmc_latest.json")
+    try:
+        with open(path) as fh:
+            m = json.load(fh)
+        if [m["C"], m["H"], m["W"], m["K"], m["pairs"]] != [C, H, W, K, n_pairs]:
+            return None
+        return (2.0 * m["FETCH_SIZE_KB"] + m["WRITE_SIZE_KB"]) * 1024.0
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def algorithmic_bytes_per_pair(C, H, W, K):
     """read feat_ref + feat_src, write out, attn, corr_pos, two 3x4 P."""
     return 3 * C * H * W * 4 + K * H * W * 4 + H * W * 8 + 96
@@ -186,7 +202,8 @@ def main():
                    "partition": args.partition, "layout": "NHWC (channels_last)", "pairs_per_gpu": n_pairs,
                    "variant": args.variant},
         "roofline": {"bound": "hbm", "kernel": "epipolar_fwd_kernel", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS,
-                     "unit": "GB/s", "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": None,
+                     "unit": "GB/s", "frac": achieved_gbs / HBM_PEAK_GBS,
+                     "traffic": measured_hbm_traffic(C, H, W, K, n_pairs),
                      "kernel_ms": kernel_ms, "kernel_ms_min": k_ms[0], "algorithmic_bytes_per_launch": bytes_launch,
                      "valu": {"achieved": achieved_tf, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
                               "frac": achieved_tf / FP32_PEAK_TFLOPS, "algorithmic_flops_per_launch": flops_launch}},

@@ -36,4 +36,13 @@ with open(out + "_summary.txt", "w") as fh:
     for (kn, cn), vals in agg.items():
         line = "%-62s %-32s n=%d mean=%.6g" % (kn, cn, len(vals), sum(vals) / len(vals))
         print(line); fh.write(line + "\n")
+import json
+get = lambda name: next((sum(v) / len(v) for (kn, cn), v in agg.items() if cn == name), None)
+if get("FETCH_SIZE") is not None and get("WRITE_SIZE") is not None:
+    json.dump({"C": 256, "H": int(os.environ.get("PROF_HW", 64)), "W": int(os.environ.get("PROF_HW", 64)),
+               "K": int(os.environ.get("PROF_K", 64)), "pairs": 128, "kernel": os.environ.get("PROF_KERNEL", "fwd"),
+               "variant": int(os.environ.get("PROF_VARIANT", 0)), "FETCH_SIZE_KB": get("FETCH_SIZE"),
+               "WRITE_SIZE_KB": get("WRITE_SIZE"), "TCC_HIT_sum": get("TCC_HIT_sum"), "TCC_MISS_sum": get("TCC_MISS_sum"),
+               "VALUBusy": get("VALUBusy"), "SQ_INSTS_VALU": get("SQ_INSTS_VALU")},
+              open(out + "_pmc.json", "w"), indent=1)
 PY
