@@ -343,3 +343,47 @@ def test_pose_backbone_multiview_forward(env, oracle_mod):
     scale = max(1.0, float(np.abs(want_heat).max()))
     assert np.abs(heat[0].cpu().numpy() - want_heat).max() <= 1e-4 * scale
     _close(depth.cpu().numpy(), want["attn"], TOL_ATTN)
+
+
+def test_mpjpe_delta_vs_reference_pipeline(env):
+    """BASELINE.json: 'MPJPE within 0.1 mm of reference'.  The frozen scene holds the REAL reference's 2-D
+    detections (reference Epipolar.forward + `ret + feat` + 1x1 head + its own peak finder, CPU).  The same
+    feature maps go through the MI355X path; both sets of detections are triangulated by the same batched DLT."""
+    import os
+
+    from conftest import GOLDEN_DIR
+    from epipolar_transformers_amd import default_cfg
+    from epipolar_transformers_amd.backbones import soft_argmax_peaks
+    from epipolar_transformers_amd.epipolar import Epipolar
+    from epipolar_transformers_amd.triangulate import mpjpe, triangulate_dlt
+
+    _lib, camera, ops = env
+    d = np.load(os.path.join(GOLDEN_DIR, "mpjpe_scene.npz"))
+    V, J, C, HS, IMG, K = [int(v) for v in d["meta"]]
+    cfg = default_cfg()
+    cfg.merge_from_list(["KEYPOINT.HEATMAP_SIZE", (HS, HS), "KEYPOINT.NFEATS", C, "EPIPOLAR.SAMPLESIZE", K,
+                         "EPIPOLAR.ATTENTION", "avg", "EPIPOLAR.PARAMETERIZED", ("z",), "EPIPOLAR.ZRESIDUAL", True,
+                         "EPIPOLAR.USE_CORRECT_NORMALIZE", True, "DATASETS.IMAGE_SIZE", (IMG, IMG)])
+    mod = Epipolar(cfg=cfg).cuda().eval()
+    mod.load_state_dict({k: torch.from_numpy(d[v]) for k, v in
+                         (("z.weight", "z_weight"), ("z.bias", "z_bias"), ("bn.weight", "bn_weight"),
+                          ("bn.bias", "bn_bias"), ("bn.running_mean", "bn_mean"), ("bn.running_var", "bn_var"))},
+                        strict=False)
+    feat = _dev(d["feat"])
+    P = torch.from_numpy(d["P"])
+    # the reference's own per-pair algebra travels with the fixture (LAPACK differs across hosts)
+    mod._cams.get = lambda *a, **k: _dev(d["cam"])
+    with torch.no_grad():
+        x, corr, depth, _ = mod.forward_fused(feat, feat.roll(-1, 0).contiguous(), P, P.roll(-1, 0))
+        heat = torch.nn.functional.conv2d(x, _dev(d["final_w"]), _dev(d["final_b"]))
+        locs, scos = soft_argmax_peaks(heat, float(d["sigma"]), 4)
+    ref_locs = torch.from_numpy(d["ref_locs"]).double()
+    assert (locs.cpu().double() - ref_locs).abs().max().item() < 1e-2        # image pixels
+    Pd = P.double()[None]
+    X_ref = triangulate_dlt(ref_locs[None], Pd, torch.from_numpy(d["ref_scores"])[None])
+    X_new = triangulate_dlt(locs.cpu().double()[None], Pd, scos.cpu()[None])
+    delta = mpjpe(X_new, X_ref).item()
+    print("MPJPE delta vs reference pipeline: %.5f mm; vs ground truth: ref %.2f mm, ours %.2f mm" %
+          (delta, mpjpe(X_ref[0], torch.from_numpy(d["joints"])).item(),
+           mpjpe(X_new[0], torch.from_numpy(d["joints"])).item()))
+    assert delta < 0.1                                                       # mm
