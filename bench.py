@@ -211,12 +211,52 @@ def main():
                   "kernel_only_pair_views_per_s": n_pairs / (kernel_ms * 1e-3)},
     }
 
+    if rank == 0:
+        result["extra"]["mpjpe_delta_mm_vs_reference"] = mpjpe_delta(dev)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(args, spec, feat_ref, src, P_ref, P_src)
     if rank == 0:
         print(json.dumps(result))
     if world > 1:
         dist.destroy_process_group()
+
+
+def mpjpe_delta(dev):
+    """'MPJPE vs ref' of BASELINE.json on the frozen synthetic 4-view scene: the real reference pipeline's 2-D
+    detections (tests/golden/mpjpe_scene.npz, made by tests/golden/make_mpjpe_scene.py) vs this path's on the same
+    feature maps, both triangulated with the same batched DLT.  Returns millimetres, or None if the scene is absent."""
+    import numpy as np
+
+    path = os.path.join(ROOT, "tests", "golden", "mpjpe_scene.npz")
+    if not os.path.exists(path):
+        return None
+    from epipolar_transformers_amd import default_cfg
+    from epipolar_transformers_amd.backbones import soft_argmax_peaks
+    from epipolar_transformers_amd.epipolar import Epipolar
+    from epipolar_transformers_amd.triangulate import mpjpe, triangulate_dlt
+
+    d = np.load(path)
+    V, J, C, HS, IMG, K = [int(v) for v in d["meta"]]
+    cfg = default_cfg()
+    cfg.merge_from_list(["KEYPOINT.HEATMAP_SIZE", (HS, HS), "KEYPOINT.NFEATS", C, "EPIPOLAR.SAMPLESIZE", K,
+                         "EPIPOLAR.ATTENTION", "avg", "EPIPOLAR.PARAMETERIZED", ("z",), "EPIPOLAR.ZRESIDUAL", True,
+                         "EPIPOLAR.USE_CORRECT_NORMALIZE", True, "DATASETS.IMAGE_SIZE", (IMG, IMG)])
+    mod = Epipolar(cfg=cfg).to(dev).eval()
+    t = lambda k: torch.from_numpy(d[k])
+    mod.load_state_dict({"z.weight": t("z_weight"), "z.bias": t("z_bias"), "bn.weight": t("bn_weight"),
+                         "bn.bias": t("bn_bias"), "bn.running_mean": t("bn_mean"), "bn.running_var": t("bn_var")},
+                        strict=False)
+    cam = t("cam").to(dev)
+    mod._cams.get = lambda *a, **k: cam          # the algebra the reference computed when the scene was frozen
+    feat, P = t("feat").to(dev), t("P")
+    with torch.no_grad():
+        x, _, _, _ = mod.forward_fused(feat, feat.roll(-1, 0).contiguous(), P, P.roll(-1, 0))
+        heat = F.conv2d(x, t("final_w").to(dev), t("final_b").to(dev))
+        locs, scos = soft_argmax_peaks(heat, float(d["sigma"]), 4)
+    Pd = P.double()[None]
+    x_ref = triangulate_dlt(t("ref_locs").double()[None], Pd, t("ref_scores")[None])
+    x_new = triangulate_dlt(locs.cpu().double()[None], Pd, scos.cpu()[None])
+    return float(mpjpe(x_new, x_ref))
 
 
 def cpu_baseline(args, spec, feat_ref, feat_src, P_ref, P_src):

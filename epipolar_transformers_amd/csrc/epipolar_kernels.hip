@@ -879,13 +879,10 @@ __global__ __launch_bounds__(kWave *kWavesPerBlock) void epipolar_fwd_multi_kern
 // is evicted, i.e. once per (pixel, source row) instead of once per sample.
 // Channel mapping here is lane + 64*i (dword-strided) so that each atomic
 // instruction of a flush covers 256 contiguous bytes.
-template <int CPD /*dwords per lane: C <= 64*CPD*/, int KPL, bool FAST, bool EMIT>
+template <int CPD /*dwords per lane: C <= 64*CPD*/, int KPL, bool FAST>
 __global__ __launch_bounds__(kWave *kWavesPerBlock) void epipolar_bwd_kernel(const BwdParams p)
 {
-    // EMIT: instead of scattering gradient rows with float atomics, emit for every (pixel, source row)
-    // run the two scalars alpha/beta with  d feat_src[u] += alpha * g_p + beta * f_p ; a gather kernel
-    // (epipolar_bwd_gather_kernel) then sums them per source pixel -- no float atomics at all.
-    extern __shared__ float s_dyn[];   // EMIT: per wave [cap] u, [cap] alpha, [cap] beta
+    // Float-atomic scatter form (no workspace needed); the default is the gather form below.
     const EtLayerDesc &d = p.d;
     const int H = d.H, W = d.W, C = d.C, K = d.K;
     const int HW = H * W;
@@ -900,9 +897,6 @@ __global__ __launch_bounds__(kWave *kWavesPerBlock) void epipolar_bwd_kernel(con
     const float *cam = p.cam + (size_t)n * ET_CAM_STRIDE;
     const __amdgpu_buffer_rsrc_t src = make_rsrc(p.fsrc + (size_t)n * HW * C, (unsigned)HW * C * 4u);
     const __amdgpu_buffer_rsrc_t gsrc = make_rsrc(p.gsrc + (size_t)n * HW * C, (unsigned)HW * C * 4u);
-    int *s_eu = reinterpret_cast<int *>(s_dyn) + (EMIT ? wave * 3 * p.cap : 0);
-    float *s_ea = reinterpret_cast<float *>(s_eu) + (EMIT ? p.cap : 0);
-    float *s_eb = s_ea + (EMIT ? p.cap : 0);
     const int row_bytes = C * 4;
     const float neg_inf = -__builtin_huge_valf();
     // lanes beyond C (only when C < 64*CPD) alias the last channel: they read
@@ -1040,18 +1034,6 @@ __global__ __launch_bounds__(kWave *kWavesPerBlock) void epipolar_bwd_kernel(con
             }
         }
         int tag[4] = {-1, -1, -1, -1};  // byte offset of the row whose gradient G[r] holds (scalar)
-        float ea[4] = {0.f, 0.f, 0.f, 0.f}, eb[4] = {0.f, 0.f, 0.f, 0.f};  // EMIT: coefficients of that row
-        int ecount = 0;
-        auto emit = [&](int r) {  // wave-uniform call
-            if (lane == 0) {
-                s_eu[ecount] = tag[r] / row_bytes;
-                s_ea[ecount] = ea[r];
-                s_eb[ecount] = eb[r];
-            }
-            ++ecount;
-            ea[r] = 0.f;
-            eb[r] = 0.f;
-        };
 
 #pragma unroll
         for (int s = 0; s < KPL; ++s) {
@@ -1063,14 +1045,10 @@ __global__ __launch_bounds__(kWave *kWavesPerBlock) void epipolar_bwd_kernel(con
                     if (need & (1 << r)) {
                         const int off = __builtin_amdgcn_readlane(tb.off[s][r], kk);
                         if (tag[r] >= 0) {
-                            if (EMIT) {
-                                emit(r);
-                            } else {
 #pragma unroll
-                                for (int c = 0; c < CPD; ++c) {
-                                    __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(G[r][c], gsrc, voff[c], tag[r], 0);
-                                    G[r][c] = 0.f;
-                                }
+                            for (int c = 0; c < CPD; ++c) {
+                                __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(G[r][c], gsrc, voff[c], tag[r], 0);
+                                G[r][c] = 0.f;
                             }
                         }
 #pragma unroll
@@ -1084,12 +1062,6 @@ __global__ __launch_bounds__(kWave *kWavesPerBlock) void epipolar_bwd_kernel(con
                 // OTHER_GRAD (epipolar.py:141-153): which of the two uses of feat_src carry gradient
                 const float ak_src = (d.src_grad_mask & 2) ? ak : 0.f;
                 const float dsk_src = (d.src_grad_mask & 1) ? dsk : 0.f;
-                if (EMIT) {
-                    ea[0] = fmaf(w0, ak_src, ea[0]); eb[0] = fmaf(w0, dsk_src, eb[0]);
-                    ea[1] = fmaf(w1, ak_src, ea[1]); eb[1] = fmaf(w1, dsk_src, eb[1]);
-                    ea[2] = fmaf(w2, ak_src, ea[2]); eb[2] = fmaf(w2, dsk_src, eb[2]);
-                    ea[3] = fmaf(w3, ak_src, ea[3]); eb[3] = fmaf(w3, dsk_src, eb[3]);
-                }
 #pragma unroll
                 for (int c = 0; c < CPD; ++c) {
                     float sv = w0 * R[0][c];
@@ -1097,41 +1069,21 @@ __global__ __launch_bounds__(kWave *kWavesPerBlock) void epipolar_bwd_kernel(con
                     sv = fmaf(w2, R[2][c], sv);
                     sv = fmaf(w3, R[3][c], sv);
                     d1[c] = fmaf(dsk, sv, d1[c]);
-                    if (!EMIT) {
-                        const float dS = fmaf(dsk_src, f1[c], ak_src * g[c]);
-                        G[0][c] = fmaf(w0, dS, G[0][c]);
-                        G[1][c] = fmaf(w1, dS, G[1][c]);
-                        G[2][c] = fmaf(w2, dS, G[2][c]);
-                        G[3][c] = fmaf(w3, dS, G[3][c]);
-                    }
+                    const float dS = fmaf(dsk_src, f1[c], ak_src * g[c]);
+                    G[0][c] = fmaf(w0, dS, G[0][c]);
+                    G[1][c] = fmaf(w1, dS, G[1][c]);
+                    G[2][c] = fmaf(w2, dS, G[2][c]);
+                    G[3][c] = fmaf(w3, dS, G[3][c]);
                 }
             }
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             if (tag[r] >= 0) {
-                if (EMIT) {
-                    emit(r);
-                } else {
 #pragma unroll
-                    for (int c = 0; c < CPD; ++c)
-                        __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(G[r][c], gsrc, voff[c], tag[r], 0);
-                }
+                for (int c = 0; c < CPD; ++c)
+                    __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(G[r][c], gsrc, voff[c], tag[r], 0);
             }
-        }
-        if (EMIT) {
-            // entries of this pixel: LDS -> global (coalesced), and one integer count per target row
-            __builtin_amdgcn_wave_barrier();
-            const size_t ebase = ((size_t)n * HW + pix) * p.cap;
-            for (int i = lane; i < ecount; i += kWave) {
-                const int u = s_eu[i];
-                p.ent_u[ebase + i] = u;
-                p.ent_a[ebase + i] = s_ea[i];
-                p.ent_b[ebase + i] = s_eb[i];
-                atomicAdd(&p.row_count[(size_t)n * HW + u], 1);
-            }
-            if (lane == 0) p.ent_count[(size_t)n * HW + pix] = ecount;
-            __builtin_amdgcn_wave_barrier();
         }
         float *gr = p.gref + ((size_t)n * HW + pix) * C;
 #pragma unroll
@@ -1638,15 +1590,10 @@ void launch_fwd(const FwdParams &p, int variant, dim3 grid, size_t lds, hipStrea
 template <int CPD, int KPL>
 void launch_bwd(const BwdParams &p, int variant, dim3 grid, hipStream_t st)
 {
-    const bool emit = p.ent_u != nullptr;
-    const size_t lds = emit ? (size_t)kWavesPerBlock * 3 * p.cap * sizeof(float) : 0;
-    if (variant & ET_VARIANT_SAFE_REDUCE) {
-        if (emit) hipLaunchKernelGGL((epipolar_bwd_kernel<CPD, KPL, false, true>), grid, dim3(256), lds, st, p);
-        else hipLaunchKernelGGL((epipolar_bwd_kernel<CPD, KPL, false, false>), grid, dim3(256), lds, st, p);
-    } else {
-        if (emit) hipLaunchKernelGGL((epipolar_bwd_kernel<CPD, KPL, true, true>), grid, dim3(256), lds, st, p);
-        else hipLaunchKernelGGL((epipolar_bwd_kernel<CPD, KPL, true, false>), grid, dim3(256), lds, st, p);
-    }
+    if (variant & ET_VARIANT_SAFE_REDUCE)
+        hipLaunchKernelGGL((epipolar_bwd_kernel<CPD, KPL, false>), grid, dim3(256), 0, st, p);
+    else
+        hipLaunchKernelGGL((epipolar_bwd_kernel<CPD, KPL, true>), grid, dim3(256), 0, st, p);
 }
 
 }  // namespace
