@@ -53,6 +53,8 @@ def parse():
     ap.add_argument("--samples", type=int, default=64)
     ap.add_argument("--variant", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--end-to-end", action="store_true",
+                    help="also time epipolarposeR-50 end to end (trunk once per view + layer + head + peaks); not the headline value")
     ap.add_argument("--cpu-pairs", type=int, default=128, help="pairs in the bounded CPU-baseline sample")
     ap.add_argument("--cpu-reps", type=int, default=2)
     return ap.parse_args()
@@ -213,12 +215,52 @@ def main():
 
     if rank == 0:
         result["extra"]["mpjpe_delta_mm_vs_reference"] = mpjpe_delta(dev)
+    if rank == 0 and args.end_to_end:
+        result["extra"]["end_to_end"] = end_to_end(args, dev, P_ref, P_src, frames, V)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(args, spec, feat_ref, src, P_ref, P_src)
     if rank == 0:
         print(json.dumps(result))
     if world > 1:
         dist.destroy_process_group()
+
+
+def end_to_end(args, dev, P_ref, P_src, frames, V):
+    """epipolarposeR-50 on `frames` x V synthetic 256x256 images (random init, fp32, eval): the trunk runs ONCE per
+    view (the reference runs it twice per pair, model.py:241-247 -- SURVEY.md N1), its channels_last deconv
+    features feed the fused layer directly, then the 1x1 head and the batched peak finder."""
+    from epipolar_transformers_amd import backbones, default_cfg
+
+    cfg = default_cfg()
+    cfg.merge_from_list(["BACKBONE.BODY", "epipolarposeR-50", "BACKBONE.PRETRAINED", False,
+                         "KEYPOINT.HEATMAP_SIZE", (args.hw, args.hw), "KEYPOINT.NUM_PTS", 17, "KEYPOINT.SIGMA", 8.0,
+                         "KEYPOINT.NFEATS", args.channels, "DATASETS.IMAGE_SIZE", (args.hw * 4, args.hw * 4),
+                         "EPIPOLAR.MERGE", "late", "EPIPOLAR.ATTENTION", "avg", "EPIPOLAR.PARAMETERIZED", ("z",),
+                         "EPIPOLAR.ZRESIDUAL", True, "EPIPOLAR.USE_CORRECT_NORMALIZE", True,
+                         "EPIPOLAR.SAMPLESIZE", args.samples])
+    net = backbones.build_backbone(cfg).to(dev).eval().to(memory_format=torch.channels_last)
+    n = frames * V
+    img = torch.randn(n, 3, args.hw * 4, args.hw * 4, device=dev).contiguous(memory_format=torch.channels_last)
+    idx = torch.arange(n, device=dev).view(frames, V).roll(-1, 1).reshape(-1)       # ring neighbour of each view
+
+    def step():
+        with torch.no_grad():
+            feats = net(img)[0]                                   # trunk + deconv head, every view once
+            x, corr, depth, _ = net.epipolar_sampler.forward_fused(feats, feats[idx], P_ref, P_src)
+            heat = net.final_layer(x)
+            return backbones.soft_argmax_peaks(heat, 8.0, 4)
+
+    for _ in range(3):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    reps = 5
+    for _ in range(reps):
+        step()
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / reps * 1e3
+    return {"ms_per_step": ms, "views_per_s": n / (ms * 1e-3), "model": "epipolarposeR-50 random init, fp32, eval",
+            "note": "trunk once per view (the reference runs it twice per pair)"}
 
 
 def mpjpe_delta(dev):
