@@ -199,8 +199,9 @@ def main():
         "value": value, "unit": "pair-views/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "configs[1]: epipolarposeR-50 head, 4 views x %d frames = %d pairs/GPU, C=%d, %dx%d, K=%d, "
-                               "z+BN+residual, eval" % (frames, n_pairs, C, H, W, K),
+        "config": {"workload": "%sepipolarposeR head, %d views x %d frames = %d pairs/GPU, C=%d, %dx%d, K=%d, "
+                               "z+BN+residual, eval" % ("configs[1]: " if (V, frames, C, H, K) == (4, 32, 256, 64, 64)
+                                                        else "", V, frames, n_pairs, C, H, W, K),
                    "partition": args.partition, "layout": "NHWC (channels_last)", "pairs_per_gpu": n_pairs,
                    "variant": args.variant},
         "roofline": {"bound": "hbm", "kernel": "epipolar_fwd_kernel", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS,

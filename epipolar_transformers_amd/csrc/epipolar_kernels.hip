@@ -1646,12 +1646,12 @@ int et_epipolar_forward(const EtLayerDesc *desc, const float *xs, const float *y
                        (size_t)kWavesPerBlock * kpl_ * kWave * 4 * sizeof(float);
     hipStream_t st = (hipStream_t)stream;
     const int cpl = (desc->C + 255) / 256, kpl = (desc->K + 63) / 64;
-    // variant 0 = the tuned default (measured on MI355X, profiles/): for the 256-channel head four pixels
-    // per wave in lockstep; otherwise one pixel per wave, batches of 4 samples, <= 96 VGPRs (5 waves/SIMD),
+    // variant 0 = the tuned default (measured on MI355X, profiles/): for the 256-channel head with K <= 64
+    // four pixels per wave in lockstep; otherwise one pixel per wave, batches of 4 samples, <= 96 VGPRs (5 waves/SIMD),
     // waves of a block interleaved over neighbouring pixels
     int v = desc->variant;
     if ((v & ~(ET_VARIANT_ABLATE_NO_LOADS | ET_VARIANT_ABLATE_ONE_ROW)) == 0)
-        v |= (desc->C == 256 && kpl <= 2) ? ET_VARIANT_MULTI4
+        v |= (desc->C == 256 && kpl == 1) ? ET_VARIANT_MULTI4   // K > 64: its LDS records cut occupancy (measured 1.8x slower)
                                           : (ET_VARIANT_BATCH4 | ET_VARIANT_OCC5 | ET_VARIANT_PIXEL_INTERLEAVE);
     if (v & ET_VARIANT_BASELINE)
         v &= ~(ET_VARIANT_BATCH4 | ET_VARIANT_OCC5 | ET_VARIANT_OCC6 | ET_VARIANT_PIXEL_INTERLEAVE |

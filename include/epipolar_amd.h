@@ -63,7 +63,7 @@ typedef struct EtLayerDesc {
 #define ET_CAM_STRIDE 27
 
 /* Variant bits (EtLayerDesc.variant).  0 selects the tuned default of the forward kernel
- * (MULTI4 for C == 256 and K <= 128, else BATCH4 | OCC5 | PIXEL_INTERLEAVE); the bits exist
+ * (MULTI4 for C == 256 and K <= 64, else BATCH4 | OCC5 | PIXEL_INTERLEAVE); the bits exist
  * for ablation and tuning runs. */
 #define ET_VARIANT_SAFE_REDUCE 1  /* cross-lane sums via ds_bpermute only (no permlane swaps / DPP) */
 #define ET_VARIANT_NO_TAP_CACHE 2 /* reload all four taps for every sample                          */
