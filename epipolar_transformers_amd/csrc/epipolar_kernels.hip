@@ -1354,8 +1354,7 @@ __global__ __launch_bounds__(256) void bwd_scan_kernel(int HW, const int *row_co
 // One wave per reference pixel: move its entries to their source rows' segments.
 __global__ __launch_bounds__(256) void bwd_bucket_kernel(int HW, int cap, int total_rows, const int *ent_count,
                                                           const int *ent_u, const float *ent_a, const float *ent_b,
-                                                          const int *row_base, int *row_cursor, int *csr_p,
-                                                          float *csr_a, float *csr_b)
+                                                          const int *row_base, int *row_cursor, int4 *csr)
 {
     const int lane = threadIdx.x & (kWave - 1);
     const int wave_global = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
@@ -1371,9 +1370,9 @@ __global__ __launch_bounds__(256) void bwd_bucket_kernel(int HW, int cap, int to
             const size_t gu = pair_rows + u;
             const int pos = row_base[gu] + atomicAdd(&row_cursor[gu], 1);
             const size_t o = pair_rows * cap + pos;     // per-pair CSR region of HW*cap slots
-            csr_p[o] = pidx * cap + slot;               // unique, run-independent ordering key
-            csr_a[o] = ent_a[ebase + slot];
-            csr_b[o] = ent_b[ebase + slot];
+            // one 16-byte record per entry (a single scattered store): {ordering key, alpha, beta, -}
+            csr[o] = make_int4(pidx * cap + slot, __float_as_int(ent_a[ebase + slot]),
+                               __float_as_int(ent_b[ebase + slot]), 0);
         }
     }
 }
@@ -1384,8 +1383,7 @@ __global__ __launch_bounds__(256) void bwd_bucket_kernel(int HW, int cap, int to
 template <int CPL>
 __global__ __launch_bounds__(256) void epipolar_bwd_gather_kernel(int HW, int C, int cap, int total_rows, int mask,
                                                                    const int *row_count, const int *row_base,
-                                                                   const int *csr_p, const float *csr_a,
-                                                                   const float *csr_b, const float *fref,
+                                                                   const int4 *csr, const float *fref,
                                                                    const float *gout, float *gsrc, int max_sort)
 {
     extern __shared__ int s_sort[];  // per wave: max_sort keys + max_sort CSR indices
@@ -1413,7 +1411,7 @@ __global__ __launch_bounds__(256) void epipolar_bwd_gather_kernel(int HW, int C,
         int npow = 1;
         while (npow < cnt) npow <<= 1;
         for (int i = lane; i < npow; i += kWave) {
-            keys[i] = (i < cnt) ? csr_p[seg + i] : 0x7fffffff;
+            keys[i] = (i < cnt) ? csr[seg + i].x : 0x7fffffff;
             vals[i] = i;
         }
         __builtin_amdgcn_wave_barrier();
@@ -1445,9 +1443,10 @@ __global__ __launch_bounds__(256) void epipolar_bwd_gather_kernel(int HW, int C,
         float aa = 0.f, bb = 0.f;
         if (lane < m) {
             idx = sorted ? vals[e0 + lane] : (e0 + lane);
-            pp = csr_p[seg + idx] / cap;
-            aa = csr_a[seg + idx];
-            bb = csr_b[seg + idx];
+            const int4 rec = csr[seg + idx];
+            pp = rec.x / cap;
+            aa = __int_as_float(rec.y);
+            bb = __int_as_float(rec.z);
         }
         for (int j = 0; j < m; ++j) {
             const int pj = __builtin_amdgcn_readlane(pp, j) * row_bytes;  // scalar row offset
@@ -1691,7 +1690,7 @@ size_t et_epipolar_backward_workspace_bytes(const EtLayerDesc *desc)
     if (validate(desc)) return 0;
     const size_t rows = (size_t)desc->N * desc->H * desc->W;
     const size_t cap = 4u * (size_t)desc->K;
-    return rows * cap * 4u * 6u + rows * 4u * 4u + 256u;
+    return rows * cap * (3u * 4u + 16u) + rows * 4u * 4u + 256u;
 }
 
 int et_epipolar_backward(const EtLayerDesc *desc, const float *xs, const float *ys, const float *steps,
@@ -1722,8 +1721,8 @@ int et_epipolar_backward(const EtLayerDesc *desc, const float *xs, const float *
     const long long total = (long long)p.blocks_per_pair * desc->N;
     if (total > 0x7fffffffLL) return fail("grid too large");
     p.total_blocks = (int)total;
-    int *row_base = nullptr, *row_cursor = nullptr, *csr_p = nullptr;
-    float *csr_a = nullptr, *csr_b = nullptr;
+    int *row_base = nullptr, *row_cursor = nullptr;
+    int4 *csr = nullptr;
     if (gather) {
         // carve the workspace: 3 pixel-major entry arrays, 3 row-major (CSR) arrays, 4 per-row int arrays
         p.cap = 4 * desc->K;
@@ -1732,9 +1731,7 @@ int et_epipolar_backward(const EtLayerDesc *desc, const float *xs, const float *
         p.ent_u = reinterpret_cast<int *>(w);        w += slots * 4;
         p.ent_a = reinterpret_cast<float *>(w);      w += slots * 4;
         p.ent_b = reinterpret_cast<float *>(w);      w += slots * 4;
-        csr_p = reinterpret_cast<int *>(w);          w += slots * 4;
-        csr_a = reinterpret_cast<float *>(w);        w += slots * 4;
-        csr_b = reinterpret_cast<float *>(w);        w += slots * 4;
+        csr = reinterpret_cast<int4 *>(w);           w += slots * 16;
         p.ent_count = reinterpret_cast<int *>(w);    w += rows * 4;
         p.row_count = reinterpret_cast<int *>(w);    w += rows * 4;
         row_base = reinterpret_cast<int *>(w);       w += rows * 4;
@@ -1776,18 +1773,18 @@ int et_epipolar_backward(const EtLayerDesc *desc, const float *xs, const float *
         const unsigned bblocks = (unsigned)((rows + kWavesPerBlock - 1) / kWavesPerBlock < 16384
                                             ? (rows + kWavesPerBlock - 1) / kWavesPerBlock : 16384);
         hipLaunchKernelGGL(bwd_bucket_kernel, dim3(bblocks), dim3(256), 0, st, HW, p.cap, (int)rows, p.ent_count,
-                           p.ent_u, p.ent_a, p.ent_b, row_base, row_cursor, csr_p, csr_a, csr_b);
+                           p.ent_u, p.ent_a, p.ent_b, row_base, row_cursor, csr);
         const int max_sort = 1024;  // entries per source pixel ordered in LDS (beyond that: arrival order)
         const unsigned gblocks = (unsigned)((rows + kWavesPerBlock - 1) / kWavesPerBlock);
         const size_t lds = (size_t)kWavesPerBlock * 2 * max_sort * sizeof(int);
         if (desc->C <= 256)
             hipLaunchKernelGGL((epipolar_bwd_gather_kernel<1>), dim3(gblocks), dim3(256), lds, st, HW, desc->C, p.cap,
-                               (int)rows, desc->src_grad_mask, p.row_count, row_base, csr_p, csr_a, csr_b, feat_ref,
-                               grad_out, grad_src, max_sort);
+                               (int)rows, desc->src_grad_mask, p.row_count, row_base, csr, feat_ref, grad_out, grad_src,
+                               max_sort);
         else
             hipLaunchKernelGGL((epipolar_bwd_gather_kernel<2>), dim3(gblocks), dim3(256), lds, st, HW, desc->C, p.cap,
-                               (int)rows, desc->src_grad_mask, p.row_count, row_base, csr_p, csr_a, csr_b, feat_ref,
-                               grad_out, grad_src, max_sort);
+                               (int)rows, desc->src_grad_mask, p.row_count, row_base, csr, feat_ref, grad_out, grad_src,
+                               max_sort);
         if (int e = check_launch("et_epipolar_backward(gather)")) return e;
     }
     return 0;
