@@ -1403,36 +1403,26 @@ __global__ __launch_bounds__(256) void epipolar_bwd_gather_kernel(int HW, int C,
     for (int c = 0; c < CPL; ++c) voff[c] = min(lane + c * kWave, nvec - 1);
 
     // order of summation: ascending (reference pixel, emission slot) -- a key that does not depend on
-    // the arrival order of the bucket pass.  (key, CSR index) pairs are sorted per wave in LDS.
+    // the arrival order of the bucket pass.  Keys are unique, so an entry's place in that order is the
+    // number of smaller keys: a rank sort (every lane compares its keys against all keys, read as LDS
+    // broadcasts, no dependent passes) is cheaper here than a bitonic network (n ~ 140).
     int *keys = s_sort + wave * 2 * max_sort;
     int *vals = keys + max_sort;
     const bool sorted = cnt <= max_sort;
     if (sorted) {
-        int npow = 1;
-        while (npow < cnt) npow <<= 1;
-        for (int i = lane; i < npow; i += kWave) {
-            keys[i] = (i < cnt) ? csr[seg + i].x : 0x7fffffff;
-            vals[i] = i;
+        const int cnt4 = (cnt + 3) & ~3;
+        for (int i = lane; i < cnt4; i += kWave) keys[i] = (i < cnt) ? csr[seg + i].x : 0x7fffffff;
+        __builtin_amdgcn_wave_barrier();
+        for (int base = 0; base < cnt; base += kWave) {
+            const int mine = (base + lane < cnt) ? keys[base + lane] : 0x7fffffff;
+            int rank = 0;
+            for (int j = 0; j < cnt4; j += 4) {
+                const int4 kq = *reinterpret_cast<const int4 *>(&keys[j]);  // same address in every lane
+                rank += (kq.x < mine) + (kq.y < mine) + (kq.z < mine) + (kq.w < mine);
+            }
+            if (base + lane < cnt) vals[rank] = base + lane;
         }
         __builtin_amdgcn_wave_barrier();
-        for (int k = 2; k <= npow; k <<= 1)
-            for (int j = k >> 1; j > 0; j >>= 1) {
-                for (int i = lane; i < npow; i += kWave) {
-                    const int l = i ^ j;
-                    if (l > i) {
-                        const int a = keys[i], b = keys[l];
-                        const bool up = (i & k) == 0;
-                        if ((a > b) == up) {
-                            keys[i] = b;
-                            keys[l] = a;
-                            const int va = vals[i];
-                            vals[i] = vals[l];
-                            vals[l] = va;
-                        }
-                    }
-                }
-                __builtin_amdgcn_wave_barrier();
-            }
     }
     const __amdgpu_buffer_rsrc_t G4 = make_rsrc(gout + (size_t)n * HW * C, (unsigned)HW * C * 4u);
     const __amdgpu_buffer_rsrc_t F4 = make_rsrc(fref + (size_t)n * HW * C, (unsigned)HW * C * 4u);
@@ -1774,9 +1764,10 @@ int et_epipolar_backward(const EtLayerDesc *desc, const float *xs, const float *
                                             ? (rows + kWavesPerBlock - 1) / kWavesPerBlock : 16384);
         hipLaunchKernelGGL(bwd_bucket_kernel, dim3(bblocks), dim3(256), 0, st, HW, p.cap, (int)rows, p.ent_count,
                            p.ent_u, p.ent_a, p.ent_b, row_base, row_cursor, csr);
-        const int max_sort = 1024;  // entries per source pixel ordered in LDS (beyond that: arrival order)
+        // entries per source pixel ordered in LDS (beyond that, or with ET_VARIANT_BWD_UNSORTED: arrival order)
+        const int max_sort = (desc->variant & ET_VARIANT_BWD_UNSORTED) ? 0 : 1024;
         const unsigned gblocks = (unsigned)((rows + kWavesPerBlock - 1) / kWavesPerBlock);
-        const size_t lds = (size_t)kWavesPerBlock * 2 * max_sort * sizeof(int);
+        const size_t lds = (size_t)kWavesPerBlock * 2 * (max_sort ? max_sort : 1) * sizeof(int);
         if (desc->C <= 256)
             hipLaunchKernelGGL((epipolar_bwd_gather_kernel<1>), dim3(gblocks), dim3(256), lds, st, HW, desc->C, p.cap,
                                (int)rows, desc->src_grad_mask, p.row_count, row_base, csr, feat_ref, grad_out, grad_src,

@@ -75,6 +75,7 @@ typedef struct EtLayerDesc {
 #define ET_VARIANT_MULTI2 1024     /* C == 256: two pixels per wave in lockstep (32 lanes x 8 channels each) */
 #define ET_VARIANT_MULTI4 2048     /* C == 256: four pixels per wave in lockstep (16 lanes x 16 channels)    */
 #define ET_VARIANT_BWD_ATOMIC 4096 /* backward: float-atomic scatter even when a workspace is given      */
+#define ET_VARIANT_BWD_UNSORTED 8192 /* backward gather: sum in arrival order (faster, not bit-reproducible) */
 #define ET_VARIANT_BASELINE 256    /* batches of 8, compiler-chosen registers, pixels 4w..4w+3 per wave   */
 #define ET_VARIANT_ABLATE_NO_LOADS 64  /* profiling only, WRONG RESULTS: no tap loads after the first sample */
 #define ET_VARIANT_ABLATE_ONE_ROW 128  /* profiling only, WRONG RESULTS: every tap load reads source row 0    */
