@@ -92,10 +92,18 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
+    # BENCH_SINGLE_DEVICE=1 / BENCH_DIST_BACKEND=gloo: debugging aid to exercise the N>1 code path on a
+    # one-GPU box (all ranks on cuda:0, gloo instead of RCCL); never used for reported numbers.
+    if os.environ.get("BENCH_SINGLE_DEVICE") == "1":
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        backend = os.environ.get("BENCH_DIST_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
     assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
 
     from epipolar_transformers_amd import _lib, camera, ops, synthetic as syn
