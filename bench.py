@@ -126,8 +126,11 @@ def main():
     if args.partition == "views" and world > 1:
         # rank owns `n_pairs` reference maps of ONE camera (or V/world cameras); sources arrive by all-gather
         exchange = ViewShardExchange(world, rank, V)
-        P_ref, P_src = exchange.select_pairs(frames * V, image, seed=1000)
+        # weak scaling: a view group (min(world, V) ranks) shares frames * min(world, V) frames, so every rank
+        # still owns frames * V (reference, source) pairs
+        P_ref, P_src = exchange.select_pairs(frames * min(world, V) * V, image, seed=1000)
         n_pairs = P_ref.shape[0]
+        assert n_pairs == frames * V
     feat_ref = torch.randn(n_pairs, H, W, C, device=dev, generator=g).relu_()      # NHWC, post-ReLU statistics
     feat_own = feat_ref                                                            # maps this rank produced
     feat_src = torch.randn(n_pairs, H, W, C, device=dev, generator=g).relu_() if exchange is None else None
