@@ -660,14 +660,21 @@ __global__ __launch_bounds__(kWave *kWavesPerBlock) void epipolar_fwd_multi_kern
     for (int round = 0; round < ROUNDS; ++round) {
         const int first = pix_base + wave * kPixPerWave + round * PPW;  // first pixel of this wave's group
         if (first >= HW) break;                                         // wave-uniform
+        // ---- the PPW epipolar segments at once: lane group g evaluates pixel g's ------------
+        {
+            const int pixg = min(first + g, HW - 1);
+            const int hg = pixg / W, wg = pixg - hg * W;
+            const et::Segment sg = et::epipolar_segment(d, cam, p.xs[wg], p.ys[hg]);
+            if (li == 0) s_seg[g] = make_float4(sg.sx, sg.sy, sg.vx, sg.vy);
+        }
+        __builtin_amdgcn_wave_barrier();
         // ---- lanes <-> samples, one pixel after the other: records into LDS ----
 #pragma unroll
         for (int gg = 0; gg < PPW; ++gg) {
-            const int pix = first + gg;
-            const bool live = pix < HW;
-            const int pc = live ? pix : HW - 1;
-            const int h = pc / W, w = pc - h * W;
-            const et::Segment seg = et::epipolar_segment(d, cam, p.xs[w], p.ys[h]);
+            const bool live = first + gg < HW;
+            const float4 sq = s_seg[gg];
+            et::Segment seg;
+            seg.sx = sq.x; seg.sy = sq.y; seg.vx = sq.z; seg.vy = sq.w;
             SampleTable<KPL> tb;
             build_sample_table<KPL, true>(d, seg, p.steps, lane, row_bytes, tb);
 #pragma unroll
@@ -677,7 +684,6 @@ __global__ __launch_bounds__(kWave *kWavesPerBlock) void epipolar_fwd_multi_kern
                 s_wt[gg * KP + k] = make_float4(tb.w[s][0], tb.w[s][1], tb.w[s][2], tb.w[s][3]);
                 s_need[gg * KP + k] = live ? tb.need[s] : 0;
             }
-            if (lane == 0) s_seg[gg] = make_float4(seg.sx, seg.sy, seg.vx, seg.vy);
         }
         __builtin_amdgcn_wave_barrier();
 
@@ -715,19 +721,19 @@ __global__ __launch_bounds__(kWave *kWavesPerBlock) void epipolar_fwd_multi_kern
             const int4 off = s_off[rec0 + k];
             if (need & 1) {
 #pragma unroll
-                for (int c = 0; c < CQ; ++c) R[0][c] = buf_load_f4(src, off.x + lane_off + c * LPP * 16, 0);
+                for (int c = 0; c < CQ; ++c) R[0][c] = buf_load_f4(src, off.x + lane_off, c * LPP * 16);
             }
             if (need & 2) {
 #pragma unroll
-                for (int c = 0; c < CQ; ++c) R[1][c] = buf_load_f4(src, off.y + lane_off + c * LPP * 16, 0);
+                for (int c = 0; c < CQ; ++c) R[1][c] = buf_load_f4(src, off.y + lane_off, c * LPP * 16);
             }
             if (need & 4) {
 #pragma unroll
-                for (int c = 0; c < CQ; ++c) R[2][c] = buf_load_f4(src, off.z + lane_off + c * LPP * 16, 0);
+                for (int c = 0; c < CQ; ++c) R[2][c] = buf_load_f4(src, off.z + lane_off, c * LPP * 16);
             }
             if (need & 8) {
 #pragma unroll
-                for (int c = 0; c < CQ; ++c) R[3][c] = buf_load_f4(src, off.w + lane_off + c * LPP * 16, 0);
+                for (int c = 0; c < CQ; ++c) R[3][c] = buf_load_f4(src, off.w + lane_off, c * LPP * 16);
             }
         };
         if (PIPE) issue_step(0);
@@ -763,11 +769,11 @@ __global__ __launch_bounds__(kWave *kWavesPerBlock) void epipolar_fwd_multi_kern
             if (d.softmax_enabled) {
                 sv = sv * d.softmax_scale;  // epipolar.py:306
                 const float m_new = fmaxf(m_run, sv);
-                if (__any(m_new > m_run)) {  // rare after the first few samples
-                    const float alpha = __expf(m_run - m_new);
+                // rescale every step (alpha == 1 when the maximum did not move): a voted lazy rescale
+                // costs more in branch + register copies than these 2*CQ packed multiplies
+                const float alpha = __expf(m_run - m_new);
 #pragma unroll
-                    for (int c = 0; c < CQ; ++c) acc[c] = f4_mul(alpha, acc[c]);
-                }
+                for (int c = 0; c < CQ; ++c) acc[c] = f4_mul(alpha, acc[c]);
                 m_run = m_new;
                 e = __expf(sv - m_new);
             } else {
