@@ -387,3 +387,39 @@ def test_mpjpe_delta_vs_reference_pipeline(env):
           (delta, mpjpe(X_ref[0], torch.from_numpy(d["joints"])).item(),
            mpjpe(X_new[0], torch.from_numpy(d["joints"])).item()))
     assert delta < 0.1                                                       # mm
+
+
+@pytest.mark.parametrize("shape", [dict(H=10, W=10, C=256, K=16), dict(H=9, W=7, C=256, K=20), dict(H=12, W=20, C=32, K=9),
+                                   dict(H=7, W=13, C=12, K=70), dict(H=5, W=6, C=260, K=8)])
+@pytest.mark.parametrize("variant", [0, 28, 2048, 1024])
+def test_ragged_shapes_vs_oracle(env, oracle_mod, shape, variant):
+    """Non-square maps, H*W not a multiple of the 16-pixel block (partial blocks and attention tiles), K not a
+    multiple of the batch, C below/above one wave of float4 -- forward, residual base and both backward forms."""
+    _lib, camera, ops = env
+    from epipolar_transformers_amd import synthetic as syn
+
+    H, W, C, K = shape["H"], shape["W"], shape["C"], shape["K"]
+    P1, P2 = syn.make_pairs(1, 4, 64, seed=21, jitter=(0.05, 2.0))
+    P1, P2 = P1[:3], P2[:3]
+    g = torch.Generator().manual_seed(H * 100 + W)
+    f1 = torch.randn(3, C, H, W, generator=g).relu()
+    f2 = torch.randn(3, C, H, W, generator=g).relu()
+    go = torch.randn(3, C, H, W, generator=g)
+    # a non-square grid in the reference means HEATMAP_SIZE=(H,W) with image (4H,4W): xs from W, ys from H
+    spec = ops.LayerSpec(H=H, W=W, K=K, variant=variant)
+    so = oracle_mod.LayerSpec(H, W, K)
+    cam = camera.pair_algebra(P1, P2)
+    want = oracle_mod.forward(so, f1, f2, None, None, cam=cam.numpy())
+    ref, src = ops.to_nhwc(f1.cuda()), ops.to_nhwc(f2.cuda())
+    out, attn, corr, base = ops.forward_nhwc(spec, ref, src, cam.cuda(), want_res_base=True)
+    assert torch.equal(base, ref)
+    _close(attn.cpu().numpy(), want["attn"], TOL_ATTN)
+    _close(out.permute(0, 3, 1, 2).cpu().numpy(), want["out"], TOL_OUT)
+    assert ((corr.cpu().numpy() != want["corr_pos"]).any(-1)).mean() <= 2e-2
+    assert np.array_equal(ops.sample_locs(spec, cam.cuda()).cpu().numpy(), want["sample_locs"])
+    g1, g2 = oracle_mod.backward(so, f1.numpy(), f2.numpy(), want["sample_locs"], go.numpy())
+    for use_ws in (True, False):
+        gr, gs = ops.backward_nhwc(spec, ref, src, cam.cuda(), ops.to_nhwc(go.cuda()), use_workspace=use_ws)
+        for got, wantg in ((gr, g1), (gs, g2)):
+            scale = max(np.abs(wantg).max(), 1e-6)
+            assert np.abs(got.permute(0, 3, 1, 2).cpu().numpy() - wantg).max() <= TOL_GRAD_REL * scale
