@@ -46,6 +46,8 @@ def parse():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--partition", choices=["frames", "views"], default="frames")
+    ap.add_argument("--exchange-chunks", type=int, default=4,
+                    help="view partition: all-gather the source maps in this many frame ranges, overlapped with the kernel")
     ap.add_argument("--frames", type=int, default=32, help="frames per GPU (4 views each)")
     ap.add_argument("--views", type=int, default=4)
     ap.add_argument("--hw", type=int, default=64)
@@ -143,9 +145,23 @@ def main():
     b_fold = (z_b * bn_scale + bn_shift).contiguous()
     P_ref_pin, P_src_pin = P_ref.pin_memory(), P_src.pin_memory()
 
-    def layer_step():
+    def layer_step_view_sharded():
+        """North-star partition: the source maps arrive by RCCL all-gather in frame ranges; the fused kernel of
+        range i runs while ranges i+1.. are still on the xGMI links."""
         cam = camera.pair_algebra(P_ref_pin, P_src_pin).pin_memory().to(dev, non_blocking=True)
-        src = feat_src if exchange is None else exchange.gather_sources(feat_own)
+        xs = []
+        for idx, src_chunk in exchange.gather_sources_chunked(feat_own, args.exchange_chunks):
+            idx = idx.to(dev)
+            out, attn, corr, base = ops.forward_nhwc(spec, feat_ref[idx], src_chunk, cam[idx].contiguous(),
+                                                     res_bias=b_fold, want_res_base=True)
+            xs.append(torch.addmm(base.view(-1, C), out.view(-1, C), w_fold_t, out=base.view(-1, C)))
+        return xs
+
+    def layer_step():
+        if exchange is not None:
+            return layer_step_view_sharded()
+        cam = camera.pair_algebra(P_ref_pin, P_src_pin).pin_memory().to(dev, non_blocking=True)
+        src = feat_src
         # fused kernel: out, attention, corr_pos and the additive term feat + bf of the residual fusion
         out, attn, corr, base = ops.forward_nhwc(spec, feat_ref, src, cam, res_bias=b_fold, want_res_base=True)
         # bn(z(out)) + out + feat  ==  (feat + bf) + out @ Wf^T : one fp32 GEMM accumulating in place

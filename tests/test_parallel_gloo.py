@@ -34,6 +34,13 @@ def _worker(rank, world, port, V, frames, errs):
         src = ex.gather_sources(own)
         want = torch.stack([_global_map(fr0 + f, (v + 1) % V) for v in ex.my_cams for f in range(frames)])
         assert torch.equal(src, want), "rank %d got wrong source maps" % rank
+        # chunked / overlappable form: same maps, delivered in frame ranges
+        got = torch.empty_like(want)
+        seen = 0
+        for idx, maps in ex.gather_sources_chunked(own, 2):
+            got[idx] = maps
+            seen += idx.numel()
+        assert seen == want.shape[0] and torch.equal(got, want), "rank %d chunked gather mismatch" % rank
         # projection matrices follow the same pairing: the source matrix of (frame, v) is the
         # reference matrix of camera (v+1) % V of the same frame
         allref = [torch.empty_like(P_ref) for _ in ex.group_ranks]
