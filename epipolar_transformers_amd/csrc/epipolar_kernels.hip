@@ -422,15 +422,17 @@ int et_epipolar_forward(const EtLayerDesc *desc, const float *xs, const float *y
     p.ablate = (v & ET_VARIANT_ABLATE_NO_LOADS) ? 1 : (v & ET_VARIANT_ABLATE_ONE_ROW) ? 2 : 0;
     p.interleave = (v & ET_VARIANT_PIXEL_INTERLEAVE) ? 1 : 0;
     if ((v & (ET_VARIANT_MULTI2 | ET_VARIANT_MULTI4)) && desc->C == 256 && kpl <= 2) {
-        // several pixels per wave; per-wave LDS: PPW * KP * 40 + PPW * 16 bytes
+        // several pixels per wave; per-wave LDS: PPW * KP * 32 + PPW * 16 bytes
         const int ppw = (v & ET_VARIANT_MULTI4) ? 4 : 2;
         const size_t lds_m = (attn ? (size_t)desc->K * kPixPerBlock * sizeof(float) : 0) +
-                             (size_t)kWavesPerBlock * (ppw * kpl * kWave * 40 + ppw * 16);
+                             (size_t)kWavesPerBlock * (ppw * kpl * kWave * 32 + ppw * 16);
+        const bool occ4 = v & ET_VARIANT_OCC5;   // multi kernels: compile for 4 waves per SIMD (128 VGPRs)
         const bool pipe = v & ET_VARIANT_PIPELINE;
 #define ET_MULTI(P, Q, KK)                                                                                     \
     do {                                                                                                       \
-        if (pipe) hipLaunchKernelGGL((epipolar_fwd_multi_kernel<P, Q, KK, true>), grid, dim3(256), lds_m, st, p);  \
-        else hipLaunchKernelGGL((epipolar_fwd_multi_kernel<P, Q, KK, false>), grid, dim3(256), lds_m, st, p);      \
+        if (pipe) hipLaunchKernelGGL((epipolar_fwd_multi_kernel<P, Q, KK, true, 1>), grid, dim3(256), lds_m, st, p);   \
+        else if (occ4) hipLaunchKernelGGL((epipolar_fwd_multi_kernel<P, Q, KK, false, 4>), grid, dim3(256), lds_m, st, p); \
+        else hipLaunchKernelGGL((epipolar_fwd_multi_kernel<P, Q, KK, false, 1>), grid, dim3(256), lds_m, st, p);    \
     } while (0)
         if (ppw == 4) { if (kpl == 1) ET_MULTI(4, 4, 1); else ET_MULTI(4, 4, 2); }
         else { if (kpl == 1) ET_MULTI(2, 2, 1); else ET_MULTI(2, 2, 2); }
