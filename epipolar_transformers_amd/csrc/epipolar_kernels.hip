@@ -1,22 +1,27 @@
 // MI355X (gfx950 / CDNA4) kernels of the Epipolar Transformer hot path and the
 // C ABI declared in include/epipolar_amd.h.  Written for wave64 only.
 //
-// Work decomposition (DESIGN.md "Kernels"):
-//   * one wavefront owns one reference pixel at a time; lanes <-> channels
-//     (float4 per lane, so C = 256 is exactly one 1 KiB coalesced row per tap);
-//   * the K samples of the pixel's epipolar segment are set up with
-//     lanes <-> samples (bit-faithful float32 geometry, epipolar_geometry.h) and
-//     broadcast back sample by sample with v_readlane;
-//   * taps are held in a 2x2 parity-addressed, tag-checked register cache so a
-//     source row is fetched once per pixel, not once per sample that touches it;
-//   * samples are processed in batches of 8: eight partial dot products are
-//     summed across the wave with a transposing butterfly (v_permlane32_swap,
-//     v_permlane16_swap, DPP), the masked soft-max is folded in online
-//     (running max + rescale) so the K x C sampled strip never exists anywhere;
-//   * the attention tile of 16 consecutive pixels is staged in LDS and written
-//     as 64-byte rows of the reference's (N,K,H,W) `depth` layout;
-//   * blockIdx is remapped so each XCD walks whole pairs (its L2 keeps the
-//     4 MiB source map of the pair it is working on).
+// Layout of this translation unit:
+//   epipolar_geometry.h    bit-faithful float32 geometry (segment, sample set-up), host+device
+//   this file              shared device helpers (cross-lane reductions, buffer addressing),
+//                          host-side dispatch and the extern "C" entry points
+//   kernels_forward.inc    fused forward: one pixel per wave (epipolar_fwd_kernel) and four
+//                          pixels per wave in lockstep (epipolar_fwd_multi_kernel)
+//   kernels_backward.inc   backward: coefficient emission + scan / bucket / ordered gather
+//                          (no float atomics), and the float-atomic scatter fallback
+//   kernels_misc.inc       sample_locs, residual epilogue, NCHW <-> NHWC
+//
+// Common ideas:
+//   * lanes <-> samples for the per-pixel geometry, lanes <-> channels for the arithmetic;
+//   * a 2x2 parity-addressed tap register cache: a source row is fetched once per pixel,
+//     not once per sample that touches it;
+//   * cross-lane sums with v_permlane32_swap / v_permlane16_swap / DPP, online masked soft-max:
+//     the K x C sampled strip never exists anywhere;
+//   * raw buffer resources with scalar row offsets (no vector address arithmetic);
+//   * the attention tile of 16 consecutive pixels is staged in LDS and written as 64-byte
+//     rows of the reference's (N,K,H,W) `depth` layout;
+//   * blockIdx is remapped so each XCD walks whole pairs (its L2 keeps the 4 MiB source map
+//     of the pair it is working on).
 #include <hip/hip_runtime.h>
 
 #include <cstdarg>
@@ -288,14 +293,6 @@ __device__ __forceinline__ float f4_dot(const float4 &a, const float4 &b)
     const f32x2 lo = f32x2{a.x, a.y} * f32x2{b.x, b.y};
     const f32x2 t = __builtin_elementwise_fma(f32x2{a.z, a.w}, f32x2{b.z, b.w}, lo);
     return t.x + t.y;
-}
-
-__device__ __forceinline__ float f4_dot_acc(const float4 &a, const float4 &b, float acc)
-{
-    acc = fmaf(a.x, b.x, acc);
-    acc = fmaf(a.y, b.y, acc);
-    acc = fmaf(a.z, b.z, acc);
-    return fmaf(a.w, b.w, acc);
 }
 
 // The kernels themselves (same translation unit and anonymous namespace):
