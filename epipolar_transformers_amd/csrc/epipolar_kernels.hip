@@ -26,6 +26,7 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstdint>
 #include <cstring>
 
@@ -258,6 +259,7 @@ __device__ __forceinline__ float4 f4_zero() { return make_float4(0.f, 0.f, 0.f, 
 // the lane's channel group by a constant 32-bit VGPR offset, so a tap fetch
 // costs no vector address arithmetic at all.
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void *base, unsigned bytes)
 {
@@ -275,6 +277,13 @@ __device__ __forceinline__ float buf_load_f1(__amdgpu_buffer_rsrc_t r, int voff,
     return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
 }
 
+__device__ __forceinline__ f32x2 buf_load_f2(__amdgpu_buffer_rsrc_t r, int voff, int soff)
+{
+    typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+    const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0);
+    return f32x2{__uint_as_float(v.x), __uint_as_float(v.y)};
+}
+
 __device__ __forceinline__ float4 f4_fma(float s, const float4 &a, const float4 &c)
 {
     return make_float4(fmaf(s, a.x, c.x), fmaf(s, a.y, c.y), fmaf(s, a.z, c.z), fmaf(s, a.w, c.w));
@@ -284,8 +293,6 @@ __device__ __forceinline__ float4 f4_mul(float s, const float4 &a)
 {
     return make_float4(s * a.x, s * a.y, s * a.z, s * a.w);
 }
-
-typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 // a . b through packed fp32: (a.xy * b.xy), fma with (a.zw, b.zw), one add
 __device__ __forceinline__ float f4_dot(const float4 &a, const float4 &b)
@@ -297,6 +304,7 @@ __device__ __forceinline__ float f4_dot(const float4 &a, const float4 &b)
 
 // The kernels themselves (same translation unit and anonymous namespace):
 #include "kernels_forward.inc"   // SampleTable, epipolar_fwd_kernel, epipolar_fwd_multi_kernel
+#include "kernels_forward_tile.inc"  // tile_order_kernel, epipolar_fwd_tile_kernel (MFMA formulation)
 #include "kernels_backward.inc"  // epipolar_bwd_kernel, epipolar_bwd_emit_kernel, bwd_scan/bucket, epipolar_bwd_gather_kernel
 #include "kernels_misc.inc"      // sample_locs_kernel, residual_epilogue_kernel, transpose_kernel
 
@@ -409,7 +417,7 @@ int et_epipolar_forward(const EtLayerDesc *desc, const float *xs, const float *y
     // variant 0 = the tuned default (measured on MI355X, profiles/): for the 256-channel head with K <= 64
     // four pixels per wave in lockstep; otherwise one pixel per wave, batches of 4 samples, <= 96 VGPRs (5 waves/SIMD),
     // waves of a block interleaved over neighbouring pixels
-    int v = desc->variant;
+    int v = desc->variant & ~(ET_VARIANT_NO_TILE | ET_VARIANT_TILE_SPLIT);
     if ((v & ~(ET_VARIANT_ABLATE_NO_LOADS | ET_VARIANT_ABLATE_ONE_ROW)) == 0)
         v |= (desc->C == 256 && kpl == 1) ? ET_VARIANT_MULTI4   // K > 64: its LDS records cut occupancy (measured 1.8x slower)
                                           : (ET_VARIANT_BATCH4 | ET_VARIANT_OCC5 | ET_VARIANT_PIXEL_INTERLEAVE);
@@ -446,6 +454,107 @@ int et_epipolar_forward(const EtLayerDesc *desc, const float *xs, const float *y
         else launch_fwd<2, 4>(p, v, grid, lds, st);
     }
     return check_launch("et_epipolar_forward");
+}
+
+// The MFMA tile path applies to the 256-channel head when one reference pixel alone can never
+// overflow the tile's row array: a pixel's K samples touch at most 4K source pixels, and a line
+// through a W x H map at most 4 per column (or per row, whichever way it runs), i.e. 4 max(W, H).
+static int *g_tile_stats = nullptr;  // tuning hook, see et_debug_tile_stats
+
+static int tile_rows_cap(const EtLayerDesc *d) { return (d->variant & ET_VARIANT_TILE_SPLIT) ? 64 : kTileRowsMax; }
+
+static bool tile_eligible(const EtLayerDesc *d)
+{
+    if (d->C != 256 || d->K > 256) return false;
+    const long long hw = (long long)d->H * d->W;
+    if (hw > 16384) return false;  // bitonic sort of one pair's pixels lives in LDS
+    const int longest = d->W > d->H ? d->W : d->H;
+    const int per_pixel = (d->K < longest) ? 4 * d->K : 4 * longest;
+    return per_pixel <= tile_rows_cap(d);
+}
+
+int et_debug_tile_stats(int32_t *device_buffer)
+{
+    g_tile_stats = device_buffer;
+    return 0;
+}
+
+size_t et_epipolar_forward_workspace_bytes(const EtLayerDesc *desc)
+{
+    if (validate(desc) || !tile_eligible(desc)) return 0;
+    const size_t tiles = ((size_t)desc->H * desc->W + kTilePix - 1) / kTilePix;
+    return (size_t)desc->N * tiles * kTilePix * sizeof(int) + 256u;
+}
+
+int et_epipolar_forward_tiled(const EtLayerDesc *desc, const float *xs, const float *ys, const float *steps,
+                              const float *cam, const float *feat_ref, const float *feat_src, float *out,
+                              float *attn, float *corr_pos, const float *res_bias, float *res_base,
+                              void *workspace, size_t workspace_bytes, void *stream)
+{
+    if (int e = validate(desc)) return e;
+    if (!xs || !ys || !steps || !cam || !feat_ref || !feat_src || !out)
+        return fail("et_epipolar_forward_tiled: NULL pointer");
+    if (res_bias && !res_base) return fail("et_epipolar_forward_tiled: res_bias given without res_base");
+    if (!tile_eligible(desc))
+        return fail("et_epipolar_forward_tiled: needs C == 256, H*W <= 16384 and 4 min(K, max(W,H)) <= %d "
+                    "(got C=%d H=%d W=%d K=%d); use et_epipolar_forward", tile_rows_cap(desc), desc->C, desc->H, desc->W, desc->K);
+    const size_t need = et_epipolar_forward_workspace_bytes(desc);
+    if (!workspace || workspace_bytes < need)
+        return fail("et_epipolar_forward_tiled: workspace of %zu bytes is smaller than the %zu required",
+                    workspace ? workspace_bytes : (size_t)0, need);
+    hipStream_t st = (hipStream_t)stream;
+    const int HW = desc->H * desc->W;
+    TileParams tp;
+    FwdParams &p = tp.f;
+    p.d = *desc;
+    p.xs = xs; p.ys = ys; p.steps = steps; p.cam = cam;
+    p.fref = feat_ref; p.fsrc = feat_src;
+    p.out = out; p.attn = attn; p.corr = corr_pos;
+    p.res_bias = res_bias; p.res_base = res_base;
+    p.interleave = 0; p.ablate = 0;
+    tp.tiles_per_pair = (HW + kTilePix - 1) / kTilePix;
+    p.blocks_per_pair = tp.tiles_per_pair;
+    const long long total = (long long)tp.tiles_per_pair * desc->N;
+    if (total > 0x7fffffffLL) return fail("grid too large");
+    p.total_blocks = (int)total;
+    tp.hw_words = (HW + 31) / 32;
+    tp.stats = g_tile_stats;
+    { const char *ab = getenv("ET_TILE_ABLATE"); tp.ablate = ab ? atoi(ab) : 0; }
+    tp.rows_cap = tile_rows_cap(desc);
+    int *perm = reinterpret_cast<int *>((reinterpret_cast<uintptr_t>(workspace) + 255) & ~(uintptr_t)255);
+    tp.perm = perm;
+    // 1. order every pair's reference pixels by their epipolar line
+    int n2 = 64;
+    while (n2 < HW) n2 <<= 1;
+    const size_t lds_sort = (size_t)n2 * sizeof(unsigned long long);
+    if (lds_sort > 48 * 1024) {
+        hipError_t ae = hipFuncSetAttribute(reinterpret_cast<const void *>(tile_order_kernel),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_sort);
+        if (ae != hipSuccess) return fail("hipFuncSetAttribute(tile_order_kernel): %s", hipGetErrorString(ae));
+    }
+    if (!(tp.ablate & 32))
+    hipLaunchKernelGGL(tile_order_kernel, dim3(desc->N), dim3(1024), lds_sort, st, *desc, xs, ys, cam, n2,
+                       tp.tiles_per_pair * kTilePix, perm);
+    if (tp.ablate & 16) return 0;
+    if (int e = check_launch("et_epipolar_forward_tiled(order)")) return e;
+    // 2. one block per tile
+    const int kpl = (desc->K + 63) / 64;
+    const size_t lds = (size_t)(kTilePix * kTileStride + kTileRowsMax + kTilePix + 4 + kTilePix * 4) * 4 +
+                       (size_t)tp.hw_words * 8 + (kpl == 1 ? (size_t)kTilePix * kWave * 8 : 0);
+#define ET_TILE(KK)                                                                                              \
+    do {                                                                                                         \
+        if (lds > 48 * 1024) {                                                                                   \
+            hipError_t ae = hipFuncSetAttribute(reinterpret_cast<const void *>(epipolar_fwd_tile_kernel<KK>),    \
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);           \
+            if (ae != hipSuccess) return fail("hipFuncSetAttribute(tile kernel): %s", hipGetErrorString(ae));    \
+        }                                                                                                        \
+        hipLaunchKernelGGL((epipolar_fwd_tile_kernel<KK>), dim3((unsigned)total), dim3(256), lds, st, tp);       \
+    } while (0)
+    if (kpl == 1) ET_TILE(1);
+    else if (kpl == 2) ET_TILE(2);
+    else ET_TILE(4);
+#undef ET_TILE
+    return check_launch("et_epipolar_forward_tiled");
 }
 
 size_t et_epipolar_backward_workspace_bytes(const EtLayerDesc *desc)

@@ -141,11 +141,24 @@ def forward_nhwc(spec: LayerSpec, ref: torch.Tensor, src: torch.Tensor, cam: tor
     if res_bias is not None:
         assert want_res_base and res_bias.is_cuda and res_bias.numel() == c and res_bias.is_contiguous()
     d = spec.desc(n, c)
+    lib = _lib.load()
+    # variant 0 (the library default) takes the MFMA tile formulation wherever it applies (C == 256 head);
+    # any explicit variant bit selects the per-pixel kernels
+    ws_bytes = int(lib.et_epipolar_forward_workspace_bytes(ctypes.byref(d))) \
+        if (d.variant & ~_lib.ET_VARIANT_TILE_SPLIT) == 0 else 0
     with torch.cuda.device(ref.device):
-        _lib.check(_lib.load().et_epipolar_forward(ctypes.byref(d), _ptr(xs), _ptr(ys), _ptr(steps), _ptr(cam),
-                                                   _ptr(ref), _ptr(src), _ptr(out), _ptr(attn), _ptr(corr),
-                                                   _ptr(res_bias), _ptr(base), _stream(ref)),
-                   "et_epipolar_forward")
+        if ws_bytes > 0:
+            ws = _workspace(ref.device, ws_bytes, "fwd")
+            _lib.check(lib.et_epipolar_forward_tiled(ctypes.byref(d), _ptr(xs), _ptr(ys), _ptr(steps), _ptr(cam),
+                                                     _ptr(ref), _ptr(src), _ptr(out), _ptr(attn), _ptr(corr),
+                                                     _ptr(res_bias), _ptr(base), _ptr(ws), ctypes.c_size_t(ws_bytes),
+                                                     _stream(ref)),
+                       "et_epipolar_forward_tiled")
+        else:
+            _lib.check(lib.et_epipolar_forward(ctypes.byref(d), _ptr(xs), _ptr(ys), _ptr(steps), _ptr(cam),
+                                               _ptr(ref), _ptr(src), _ptr(out), _ptr(attn), _ptr(corr),
+                                               _ptr(res_bias), _ptr(base), _stream(ref)),
+                       "et_epipolar_forward")
     if want_res_base:
         return out, attn, corr, base
     return out, attn, corr
@@ -154,10 +167,10 @@ def forward_nhwc(spec: LayerSpec, ref: torch.Tensor, src: torch.Tensor, cam: tor
 _workspaces = {}
 
 
-def _workspace(device, nbytes: int) -> torch.Tensor:
+def _workspace(device, nbytes: int, tag: str = "bwd") -> torch.Tensor:
     """Scratch for the gather-form backward, grown on demand and kept per device (288 GB of HBM: a few GB
     of scratch is cheap; all use is stream-ordered on the caller's stream)."""
-    key = str(device)
+    key = (str(device), tag)
     buf = _workspaces.get(key)
     if buf is None or buf.numel() < nbytes:
         _workspaces[key] = buf = torch.empty(nbytes, dtype=torch.uint8, device=device)

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define ET_ABI_VERSION 3
+#define ET_ABI_VERSION 4
 
 /* Static description of one layer call: the cfg keys the reference reads in
  * Epipolar.__init__ (epipolar.py:12-54) and at call time (epipolar.py:303-311,
@@ -76,6 +76,8 @@ typedef struct EtLayerDesc {
 #define ET_VARIANT_MULTI4 2048     /* C == 256: four pixels per wave in lockstep (16 lanes x 16 channels)    */
 #define ET_VARIANT_BWD_ATOMIC 4096 /* backward: float-atomic scatter even when a workspace is given      */
 #define ET_VARIANT_BWD_UNSORTED 8192 /* backward gather: sum in arrival order (faster, not bit-reproducible) */
+#define ET_VARIANT_NO_TILE 16384  /* host wrappers: do not route C == 256 calls to et_epipolar_forward_tiled */
+#define ET_VARIANT_TILE_SPLIT 32768 /* et_epipolar_forward_tiled, testing: 64-row tiles, so that tiles overflow and split */
 #define ET_VARIANT_BASELINE 256    /* batches of 8, compiler-chosen registers, pixels 4w..4w+3 per wave   */
 #define ET_VARIANT_ABLATE_NO_LOADS 64  /* profiling only, WRONG RESULTS: no tap loads after the first sample */
 #define ET_VARIANT_ABLATE_ONE_ROW 128  /* profiling only, WRONG RESULTS: every tap load reads source row 0    */
@@ -107,6 +109,21 @@ int et_epipolar_forward(const EtLayerDesc *desc, const float *xs, const float *y
                         const float *cam, const float *feat_ref, const float *feat_src, float *out,
                         float *attn, float *corr_pos, const float *res_bias, float *res_base,
                         void *stream);
+
+/* The same operator in its MFMA tile formulation (C == 256 head): reference pixels are ordered by
+ * their epipolar line, 32 neighbouring lines form a tile, and the channel-long work of the tile runs
+ * as two fp32 GEMMs on the matrix cores against the union of the source rows the tile touches
+ * (each source row is fetched per tile, not per pixel).  Same arguments and results as
+ * et_epipolar_forward (rounding differs at the 1e-6 level: the sums are re-associated), plus
+ *   workspace : device scratch of at least et_epipolar_forward_workspace_bytes(desc) bytes
+ *               (the per-pair pixel order).
+ * et_epipolar_forward_workspace_bytes returns 0 when the tile path does not apply to `desc`
+ * (then et_epipolar_forward_tiled fails and et_epipolar_forward is the path to call). */
+size_t et_epipolar_forward_workspace_bytes(const EtLayerDesc *desc);
+int et_epipolar_forward_tiled(const EtLayerDesc *desc, const float *xs, const float *ys, const float *steps,
+                              const float *cam, const float *feat_ref, const float *feat_src, float *out,
+                              float *attn, float *corr_pos, const float *res_bias, float *res_base,
+                              void *workspace, size_t workspace_bytes, void *stream);
 
 /* Backward of et_epipolar_forward w.r.t. both feature maps (sample locations
  * carry no gradient, epipolar.py:178-183).  Everything is recomputed from the
@@ -151,6 +168,11 @@ int et_nhwc_to_nchw(int32_t N, int32_t C, int32_t H, int32_t W, const float *src
 int et_debug_host_sample_setup(const EtLayerDesc *desc, const float *xs, const float *ys,
                                const float *steps, const float *cam, int32_t h, int32_t w,
                                int32_t *taps, float *weights, float *locs);
+
+/* Tuning hook (not thread-safe, leave NULL in production): while a DEVICE buffer of one int32 per
+ * tile (N * ceil(H*W/32)) is registered, et_epipolar_forward_tiled records  U | groups << 16  per tile:
+ * the size of the tile's source-row set and the number of groups it had to be split into. */
+int et_debug_tile_stats(int32_t *device_buffer);
 
 #ifdef __cplusplus
 }

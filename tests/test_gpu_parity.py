@@ -233,7 +233,7 @@ def _full_inputs(frames, views, H, C, image, seed):
 @pytest.mark.parametrize("shape", [dict(H=64, C=256, K=64, image=256, views=4, name="config2 R50 256x256"),
                                    dict(H=96, C=256, K=64, image=384, views=4, name="config4 R152 384x384"),
                                    dict(H=128, C=256, K=128, image=512, views=8, name="config5 stress")])
-@pytest.mark.parametrize("variant", [0, 28, 1024, 2048, 256])
+@pytest.mark.parametrize("variant", [0, 16384, 28, 1024, 2048, 256])
 def test_full_shape_pairs_vs_oracle(env, oracle_mod, shape, variant):
     """BASELINE.json configs 2/4/5 at their real C, HxW and K, on a few pairs the
     oracle finishes in seconds (full tensors compared)."""
@@ -242,7 +242,9 @@ def test_full_shape_pairs_vs_oracle(env, oracle_mod, shape, variant):
     P1, P2, f1, f2 = _full_inputs(1, shape["views"], H, C, shape["image"], seed=11)
     P1, P2, f1, f2 = P1[:2], P2[:2], f1[:2], f2[:2]
     f1[0, :, 5, 7] = 0
-    spec = ops.LayerSpec(H=H, W=H, K=K, variant=variant)     # 0: default (4 pixels/wave at C=256), 28: 1 pixel/wave
+    # 0: default (MFMA tiles where eligible: configs 2 and 4), 16384: default per-pixel kernel (4 pixels/wave
+    # at C=256, K<=64), 28: 1 pixel/wave
+    spec = ops.LayerSpec(H=H, W=H, K=K, variant=variant)
     cam = camera.pair_algebra(P1, P2).cuda()
     ref, src = ops.to_nhwc(f1.cuda()), ops.to_nhwc(f2.cuda())
     bias = torch.linspace(-1, 1, C, device="cuda")
@@ -390,15 +392,20 @@ def test_mpjpe_delta_vs_reference_pipeline(env):
 
 
 @pytest.mark.parametrize("shape", [dict(H=10, W=10, C=256, K=16), dict(H=9, W=7, C=256, K=20), dict(H=12, W=20, C=32, K=9),
-                                   dict(H=7, W=13, C=12, K=70), dict(H=5, W=6, C=260, K=8)])
-@pytest.mark.parametrize("variant", [0, 28, 2048, 1024])
+                                   dict(H=7, W=13, C=12, K=70), dict(H=5, W=6, C=260, K=8),
+                                   dict(H=32, W=32, C=256, K=128), dict(H=20, W=24, C=256, K=200)])
+@pytest.mark.parametrize("variant", [0, 32768, 16384, 28, 2048, 1024])
 def test_ragged_shapes_vs_oracle(env, oracle_mod, shape, variant):
-    """Non-square maps, H*W not a multiple of the 16-pixel block (partial blocks and attention tiles), K not a
-    multiple of the batch, C below/above one wave of float4 -- forward, residual base and both backward forms."""
+    """Non-square maps, H*W not a multiple of the 16-pixel block / 32-pixel tile (partial blocks, padded tiles),
+    K not a multiple of the batch, K > 64 on the tile path, C below/above one wave of float4 -- forward,
+    residual base and both backward forms.  Variant 0 takes the MFMA tile kernel for the C=256 shapes, 32768
+    the same with 64-row tiles (tiles overflow and are split into pixel groups), 16384 the per-pixel default."""
     _lib, camera, ops = env
     from epipolar_transformers_amd import synthetic as syn
 
     H, W, C, K = shape["H"], shape["W"], shape["C"], shape["K"]
+    if variant == 32768 and (C != 256 or 4 * min(K, max(H, W)) > 64):
+        pytest.skip("64-row tile splitting applies to C=256 with 4*min(K, max(H,W)) <= 64")
     P1, P2 = syn.make_pairs(1, 4, 64, seed=21, jitter=(0.05, 2.0))
     P1, P2 = P1[:3], P2[:3]
     g = torch.Generator().manual_seed(H * 100 + W)
@@ -423,3 +430,47 @@ def test_ragged_shapes_vs_oracle(env, oracle_mod, shape, variant):
         for got, wantg in ((gr, g1), (gs, g2)):
             scale = max(np.abs(wantg).max(), 1e-6)
             assert np.abs(got.permute(0, 3, 1, 2).cpu().numpy() - wantg).max() <= TOL_GRAD_REL * scale
+
+
+def test_tile_path_statistics_and_split(env):
+    """The MFMA tile path: epipolar-line ordering keeps the row set of a 32-pixel tile small (no tile of the
+    headline geometry overflows 256 rows), and the 64-row test variant really exercises the group splitting
+    while giving the same results."""
+    import ctypes
+
+    _lib, camera, ops = env
+    lib = _lib.load()
+    P1, P2, f1, f2 = _full_inputs(1, 4, 64, 256, 256, seed=13)
+    cam = camera.pair_algebra(P1, P2).cuda()
+    ref, src = ops.to_nhwc(f1.cuda()), ops.to_nhwc(f2.cuda())
+    n = P1.shape[0]
+    stats = torch.zeros(n * 128, dtype=torch.int32, device="cuda")
+    lib.et_debug_tile_stats(ctypes.c_void_p(stats.data_ptr()))
+    try:
+        out, attn, corr = ops.forward_nhwc(ops.LayerSpec(H=64, W=64, K=64), ref, src, cam)
+        torch.cuda.synchronize()
+    finally:
+        lib.et_debug_tile_stats(None)
+    st = stats.cpu().numpy()
+    rows, groups = st & 0xFFFF, st >> 16
+    assert groups.max() == 1 and rows.max() <= 256
+    assert rows[rows > 0].mean() < 200            # a pixel alone touches ~130 rows: the tiles are tight
+    # small map, 64-row tiles: most tiles must split
+    H = W = 16
+    P1, P2 = _full_inputs(1, 4, H, 256, 64, seed=14)[:2]
+    g = torch.Generator().manual_seed(3)
+    r16 = torch.randn(4, H, W, 256, generator=g).relu().cuda()
+    s16 = torch.randn(4, H, W, 256, generator=g).relu().cuda()
+    cam16 = camera.pair_algebra(P1, P2).cuda()
+    stats = torch.zeros(4 * 8, dtype=torch.int32, device="cuda")
+    lib.et_debug_tile_stats(ctypes.c_void_p(stats.data_ptr()))
+    try:
+        o_split, a_split, _ = ops.forward_nhwc(ops.LayerSpec(H=H, W=W, K=16, variant=32768), r16, s16, cam16)
+        torch.cuda.synchronize()
+    finally:
+        lib.et_debug_tile_stats(None)
+    assert (stats.cpu().numpy() >> 16).max() > 1, "no tile was split: the test does not cover the group loop"
+    o_full, a_full, _ = ops.forward_nhwc(ops.LayerSpec(H=H, W=W, K=16), r16, s16, cam16)
+    o_pp, a_pp, _ = ops.forward_nhwc(ops.LayerSpec(H=H, W=W, K=16, variant=16384), r16, s16, cam16)
+    for o, a in ((o_split, a_split), (o_full, a_full)):
+        assert (o - o_pp).abs().max().item() <= TOL_OUT and (a - a_pp).abs().max().item() <= TOL_ATTN
