@@ -103,14 +103,50 @@ ET_HD Segment epipolar_segment(const EtLayerDesc &d, const float *cam, float gx,
     return s;
 }
 
-// epipolar.py:411-414: /resize, coord2pix (multiview.py:163), normalize (multiview.py:30-35)
-ET_HD float to_normalized(const EtLayerDesc &d, float v, int size)
+// Dividing by a power of two is the same float32 operation as multiplying by its (exact) reciprocal,
+// bit for bit, and costs one instruction instead of ~10.  The resize / downsample factors of every
+// reference config are powers of two (1, 2, 4); kernels that care test this once per launch.
+struct Pow2Recips {
+    float resize, predict, down;  // reciprocals, valid when ok
+    bool ok;
+};
+
+ET_HD bool is_pow2(float v)
 {
-    v = v / d.image_resize;
-    v = v / d.predict_resize;
-    v = (v + 0.5f - d.downsample / 2.0f) / d.downsample;
+    int e;
+    return v > 0.f && frexpf(v, &e) == 0.5f && e > -100 && e < 100;
+}
+
+ET_HD Pow2Recips pow2_recips(const EtLayerDesc &d)
+{
+    Pow2Recips r;
+    r.ok = is_pow2(d.image_resize) && is_pow2(d.predict_resize) && is_pow2(d.downsample);
+    r.resize = 1.f / d.image_resize;
+    r.predict = 1.f / d.predict_resize;
+    r.down = 1.f / d.downsample;
+    return r;
+}
+
+// epipolar.py:411-414: /resize, coord2pix (multiview.py:163), normalize (multiview.py:30-35)
+template <bool P2>
+ET_HD float to_normalized_t(const EtLayerDesc &d, float v, int size, const Pow2Recips &pr)
+{
+    if (P2) {
+        v = v * pr.resize;
+        v = v * pr.predict;
+        v = (v + 0.5f - d.downsample / 2.0f) * pr.down;
+    } else {
+        v = v / d.image_resize;
+        v = v / d.predict_resize;
+        v = (v + 0.5f - d.downsample / 2.0f) / d.downsample;
+    }
     if (d.correct_normalize) return -1.f + 2.f * v / (float)(size - 1);
     return -1.f + 2.f * (v + 0.5f) / (float)size;
+}
+
+ET_HD float to_normalized(const EtLayerDesc &d, float v, int size)
+{
+    return to_normalized_t<false>(d, v, size, Pow2Recips());
 }
 
 // de_normalize (multiview.py:50-57), used for corr_pos
@@ -143,14 +179,21 @@ struct SampleSetup {
     float nx, ny;
 };
 
-ET_HD SampleSetup sample_setup(const EtLayerDesc &d, const Segment &s, float step)
+// normalised location of one sample along the segment (epipolar.py:409-414)
+template <bool P2>
+ET_HD void sample_location(const EtLayerDesc &d, const Segment &s, float step, const Pow2Recips &pr, float &nx, float &ny)
 {
-    SampleSetup o;
     // start + vec * step (epipolar.py:409): product rounded, then the sum
     const float lx = s.sx + s.vx * step;
     const float ly = s.sy + s.vy * step;
-    o.nx = to_normalized(d, lx, d.W);
-    o.ny = to_normalized(d, ly, d.H);
+    nx = to_normalized_t<P2>(d, lx, d.W, pr);
+    ny = to_normalized_t<P2>(d, ly, d.H, pr);
+}
+
+ET_HD SampleSetup sample_setup(const EtLayerDesc &d, const Segment &s, float step)
+{
+    SampleSetup o;
+    sample_location<false>(d, s, step, Pow2Recips(), o.nx, o.ny);
     const float x = unnormalize(o.nx, d.W, d.align_corners);
     const float y = unnormalize(o.ny, d.H, d.align_corners);
     const float xw = floorf(x), yn = floorf(y);

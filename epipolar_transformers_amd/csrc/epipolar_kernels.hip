@@ -29,6 +29,7 @@
 #include <cstdlib>
 #include <cstdint>
 #include <cstring>
+#include <type_traits>
 
 #include "epipolar_amd.h"
 #include "epipolar_geometry.h"

@@ -15,7 +15,7 @@ echo "== pytest gpu"; timeout 1500 python -m pytest tests -m gpu -q --timeout 60
 tail -25 "$OUT/pytest_gpu_$TAG.log"
 echo "== bench"; timeout 900 python bench.py --steps 30 --warmup 5 > "$OUT/bench_$TAG.json" 2> "$OUT/bench_$TAG.err"; echo "bench exit $?"
 cat "$OUT/bench_$TAG.json"; tail -5 "$OUT/bench_$TAG.err"
-for v in 256 258; do
+for v in 16384 256; do   # 16384: per-pixel default kernel (no MFMA tiles), 256: per-pixel baseline variant
   timeout 600 python bench.py --steps 10 --warmup 3 --variant $v --no-cpu-baseline > "$OUT/bench_${TAG}_variant$v.json" 2>> "$OUT/bench_$TAG.err"
   python - <<PY
 import json

@@ -9,14 +9,12 @@ i=0
 for grp in \
   "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA" \
   "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_INSTS_SMEM SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VMEM" \
-  "GRBM_GUI_ACTIVE GRBM_COUNT" \
+  "SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES" \
   "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_EA0_RDREQ_sum" \
   "FETCH_SIZE" \
   "WRITE_SIZE" \
   "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_TOTAL_ACCESSES_sum TCP_PENDING_STALL_CYCLES_sum" \
-  "TA_BUSY_avr TA_TA_BUSY_sum TCP_GATE_EN1_sum TCP_TA_DATA_STALL_CYCLES_sum" \
-  "VALUBusy SALUBusy MemUnitBusy MemUnitStalled" \
-  "OccupancyPercent L2CacheHit LDSBankConflict VALUUtilization"
+  "VALUBusy MfmaUtil LDSBankConflict OccupancyPercent"
 do
   i=$((i+1))
   timeout 300 rocprofv3 --pmc $grp --output-format csv -d "$OUT/pmc_${TAG}/g$i" -o pmc -- python "$ROOT/scripts/profile_kernel.py" > "$OUT/pmc_${TAG}_g$i.log" 2>&1
