@@ -462,7 +462,9 @@ int et_epipolar_forward(const EtLayerDesc *desc, const float *xs, const float *y
 // through a W x H map at most 4 per column (or per row, whichever way it runs), i.e. 4 max(W, H).
 static int *g_tile_stats = nullptr;  // tuning hook, see et_debug_tile_stats
 
-static int tile_rows_cap(const EtLayerDesc *d) { return (d->variant & ET_VARIANT_TILE_SPLIT) ? 64 : kTileRowsMax; }
+// rows per tile the kernel is instantiated with: 256 up to 64 x 64 maps, 384 beyond (longer lines)
+static int tile_rows(const EtLayerDesc *d) { return (d->W > 64 || d->H > 64) ? kTileRowsLarge : kTileRowsSmall; }
+static int tile_rows_cap(const EtLayerDesc *d) { return (d->variant & ET_VARIANT_TILE_SPLIT) ? 64 : tile_rows(d); }
 
 static bool tile_eligible(const EtLayerDesc *d)
 {
@@ -540,20 +542,27 @@ int et_epipolar_forward_tiled(const EtLayerDesc *desc, const float *xs, const fl
     if (int e = check_launch("et_epipolar_forward_tiled(order)")) return e;
     // 2. one block per tile
     const int kpl = (desc->K + 63) / 64;
-    const size_t lds = (size_t)(kTilePix * kTileStride + kTileRowsMax + kTilePix + 4 + kTilePix * 4) * 4 +
+    const int rows = tile_rows(desc);
+    const size_t lds = (size_t)(kTilePix * (rows + 1) + rows + kTilePix + 4 + kTilePix * 4) * 4 +
                        (size_t)tp.hw_words * 8 + (kpl == 1 ? (size_t)kTilePix * kWave * 8 : 0);
-#define ET_TILE(KK)                                                                                              \
+#define ET_TILE(KK, RR)                                                                                          \
     do {                                                                                                         \
         if (lds > 48 * 1024) {                                                                                   \
-            hipError_t ae = hipFuncSetAttribute(reinterpret_cast<const void *>(epipolar_fwd_tile_kernel<KK>),    \
+            hipError_t ae = hipFuncSetAttribute(reinterpret_cast<const void *>(epipolar_fwd_tile_kernel<KK, RR>), \
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);           \
             if (ae != hipSuccess) return fail("hipFuncSetAttribute(tile kernel): %s", hipGetErrorString(ae));    \
         }                                                                                                        \
-        hipLaunchKernelGGL((epipolar_fwd_tile_kernel<KK>), dim3((unsigned)total), dim3(256), lds, st, tp);       \
+        hipLaunchKernelGGL((epipolar_fwd_tile_kernel<KK, RR>), dim3((unsigned)total), dim3(256), lds, st, tp);   \
     } while (0)
-    if (kpl == 1) ET_TILE(1);
-    else if (kpl == 2) ET_TILE(2);
-    else ET_TILE(4);
+    if (rows == kTileRowsSmall) {
+        if (kpl == 1) ET_TILE(1, kTileRowsSmall);
+        else if (kpl == 2) ET_TILE(2, kTileRowsSmall);
+        else ET_TILE(4, kTileRowsSmall);
+    } else {
+        if (kpl == 1) ET_TILE(1, kTileRowsLarge);
+        else if (kpl == 2) ET_TILE(2, kTileRowsLarge);
+        else ET_TILE(4, kTileRowsLarge);
+    }
 #undef ET_TILE
     return check_launch("et_epipolar_forward_tiled");
 }

@@ -11,7 +11,7 @@ from epipolar_transformers_amd import _lib, camera, ops, synthetic
 if __name__ == "__main__":
     dev = torch.device("cuda:0")
     cases = [(2, 64, 64, True, 4), (4, 64, 64, False, 4), (3, 32, 128, True, 4), (2, 48, 33, True, 4),
-             (4, 16, 16, True, 8), (128, 64, 64, True, 4)]
+             (4, 16, 16, True, 8), (4, 96, 64, True, 4), (128, 64, 64, True, 4)]
     for (frames_views, hw, K, sm, views) in cases:
         N = frames_views
         spec = ops.LayerSpec(H=hw, W=hw, K=K, softmax_enabled=sm)
@@ -55,6 +55,15 @@ if __name__ == "__main__":
             import numpy as np
             print("  tiles %d: U mean %.1f p50 %d p90 %d max %d; groups>1: %d tiles (max %d)" % (
                 tiles, U.mean(), np.percentile(U, 50), np.percentile(U, 90), U.max(), int((ng > 1).sum()), ng.max()))
+            for wb in (True, False):
+                for _ in range(3):
+                    ops.forward_nhwc(spec, ref, src, cam, res_bias=bias if wb else None, want_res_base=wb)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(20):
+                    ops.forward_nhwc(spec, ref, src, cam, res_bias=bias if wb else None, want_res_base=wb)
+                torch.cuda.synchronize()
+                print("  tile, res_base %s: %.3f ms" % (wb, (time.perf_counter() - t0) * 50), flush=True)
             for ab, sg in ((0, 0), (1, 0), (2, 0), (4, 0), (7, 0)):
                 os.environ["ET_TILE_ABLATE"] = str(ab)
                 os.environ["ET_TILE_STAGGER"] = str(sg)
