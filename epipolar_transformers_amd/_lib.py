@@ -29,7 +29,7 @@ ET_VARIANT_BWD_ATOMIC = 4096
 ET_VARIANT_BWD_UNSORTED = 8192
 ET_VARIANT_NO_TILE = 16384
 ET_VARIANT_TILE_SPLIT = 32768
-ET_ABI_VERSION = 4
+ET_ABI_VERSION = 5
 
 
 class EpipolarAmdError(RuntimeError):
@@ -60,6 +60,8 @@ _SIGNATURES = {
     "et_epipolar_forward": (ctypes.c_int, [_D, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "et_epipolar_forward_workspace_bytes": (ctypes.c_size_t, [_D]),
     "et_epipolar_forward_tiled": (ctypes.c_int, [_D] + [_P] * 12 + [ctypes.c_size_t, _P]),
+    "et_epipolar_backward_tiled_workspace_bytes": (ctypes.c_size_t, [_D]),
+    "et_epipolar_backward_tiled": (ctypes.c_int, [_D, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, ctypes.c_size_t, _P]),
     "et_epipolar_backward_workspace_bytes": (ctypes.c_size_t, [_D]),
     "et_epipolar_backward": (ctypes.c_int, [_D, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, ctypes.c_size_t, _P]),
     "et_residual_epilogue": (ctypes.c_int, [ctypes.c_int64, ctypes.c_int32, _P, _P, _P, _P, _P, _P, _P, _P]),

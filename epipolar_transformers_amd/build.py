@@ -18,7 +18,8 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(PKG)
 SRC = [os.path.join(PKG, "csrc", "epipolar_kernels.hip")]
 DEPS = SRC + [os.path.join(PKG, "csrc", f) for f in ("epipolar_geometry.h", "kernels_forward.inc",
-                                                      "kernels_forward_tile.inc", "kernels_backward.inc", "kernels_misc.inc")] + \
+                                                      "kernels_forward_tile.inc", "kernels_backward.inc", "kernels_backward_tile.inc",
+                                                      "kernels_misc.inc")] + \
     [os.path.join(ROOT, "include", "epipolar_amd.h")]
 LIB = os.path.join(PKG, "lib", "libepipolar_amd.so")
 ARCH = "gfx950"

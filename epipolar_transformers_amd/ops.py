@@ -177,7 +177,17 @@ def _workspace(device, nbytes: int, tag: str = "bwd") -> torch.Tensor:
     return buf
 
 
-def backward_nhwc(spec: LayerSpec, ref, src, cam, grad_out, use_workspace=True):
+_BWD_EXPLICIT = _lib.ET_VARIANT_BWD_ATOMIC | _lib.ET_VARIANT_BWD_UNSORTED | _lib.ET_VARIANT_NO_TILE
+
+
+def backward_nhwc(spec: LayerSpec, ref, src, cam, grad_out, use_workspace=True, form=None):
+    """d(feat_ref), d(feat_src) of forward_nhwc.  Three forms of the same gradient:
+      "tile"    MFMA tile formulation, d(feat_src) accumulated with float atomics across tiles: fastest,
+                reproducible to rounding only (C == 256, K <= 64);
+      "gather"  per-(pixel,row) coefficients -> counting sort -> ordered per-row sums: no float atomics, bit-reproducible;
+      "atomic"  bilinear-transpose scatter with float atomics (no workspace).
+    form=None picks "tile" where it applies (unless the spec's variant names a backward form or NO_TILE), else
+    "gather"; use_workspace=False means "atomic"."""
     n, h, w, c = ref.shape
     xs, ys, steps = spec.constants(ref.device)
     grad_out = grad_out.contiguous()
@@ -185,15 +195,30 @@ def backward_nhwc(spec: LayerSpec, ref, src, cam, grad_out, use_workspace=True):
     g_src = torch.empty_like(src)
     d = spec.desc(n, c)
     lib = _lib.load()
-    ws, ws_bytes = None, 0
-    if use_workspace:
-        ws_bytes = int(lib.et_epipolar_backward_workspace_bytes(ctypes.byref(d)))
-        ws = _workspace(ref.device, ws_bytes)
+    tile_bytes = int(lib.et_epipolar_backward_tiled_workspace_bytes(ctypes.byref(d)))
+    if form is None:
+        if not use_workspace:
+            form = "atomic"
+        else:
+            form = "tile" if tile_bytes > 0 and not (d.variant & _BWD_EXPLICIT) else "gather"
+    if form not in ("tile", "gather", "atomic"):
+        raise ValueError("unknown backward form %r" % (form,))
+    args = (ctypes.byref(d), _ptr(xs), _ptr(ys), _ptr(steps), _ptr(cam), _ptr(ref), _ptr(src), _ptr(grad_out),
+            _ptr(g_ref), _ptr(g_src))
     with torch.cuda.device(ref.device):
-        _lib.check(lib.et_epipolar_backward(ctypes.byref(d), _ptr(xs), _ptr(ys), _ptr(steps), _ptr(cam),
-                                            _ptr(ref), _ptr(src), _ptr(grad_out), _ptr(g_ref), _ptr(g_src),
-                                            _ptr(ws), ctypes.c_size_t(ws_bytes), _stream(ref)),
-                   "et_epipolar_backward")
+        if form == "tile":
+            if tile_bytes == 0:
+                raise _lib.EpipolarAmdError("the tiled backward needs C == 256 and K <= 64 (got C=%d, K=%d)" % (c, spec.K))
+            ws = _workspace(ref.device, tile_bytes, "fwd")
+            _lib.check(lib.et_epipolar_backward_tiled(*args, _ptr(ws), ctypes.c_size_t(tile_bytes), _stream(ref)),
+                       "et_epipolar_backward_tiled")
+        else:
+            ws, ws_bytes = None, 0
+            if form == "gather":
+                ws_bytes = int(lib.et_epipolar_backward_workspace_bytes(ctypes.byref(d)))
+                ws = _workspace(ref.device, ws_bytes)
+            _lib.check(lib.et_epipolar_backward(*args, _ptr(ws), ctypes.c_size_t(ws_bytes), _stream(ref)),
+                       "et_epipolar_backward")
     return g_ref, g_src
 
 

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define ET_ABI_VERSION 4
+#define ET_ABI_VERSION 5
 
 /* Static description of one layer call: the cfg keys the reference reads in
  * Epipolar.__init__ (epipolar.py:12-54) and at call time (epipolar.py:303-311,
@@ -143,6 +143,19 @@ int et_epipolar_backward(const EtLayerDesc *desc, const float *xs, const float *
                          const float *cam, const float *feat_ref, const float *feat_src,
                          const float *grad_out, float *grad_ref, float *grad_src, void *workspace,
                          size_t workspace_bytes, void *stream);
+
+/* The backward in the same MFMA tile formulation (C == 256, K <= 64): per 32-pixel tile the similarity and
+ * g.S_k come from two GEMMs against the tile's source rows, d(feat_ref) from a third, and d(feat_src) from
+ * two pixel-contracting GEMMs whose U x C results are added into grad_src with float atomics (grad_src is
+ * zero-filled first).  ~50x fewer atomics than the scatter form and ~3x faster than the gather form, but the
+ * cross-tile summation order is not fixed: reproducible to rounding only.  Same arguments as
+ * et_epipolar_backward; workspace of et_epipolar_backward_tiled_workspace_bytes(desc) bytes (0: the tile path
+ * does not apply to `desc`, call et_epipolar_backward). */
+size_t et_epipolar_backward_tiled_workspace_bytes(const EtLayerDesc *desc);
+int et_epipolar_backward_tiled(const EtLayerDesc *desc, const float *xs, const float *ys, const float *steps,
+                               const float *cam, const float *feat_ref, const float *feat_src,
+                               const float *grad_out, float *grad_ref, float *grad_src, void *workspace,
+                               size_t workspace_bytes, void *stream);
 
 /* Residual fusion epilogue: x = feat + out + (y * scale[c] + shift[c])
  *   (epipolar.py:250-253 with ZRESIDUAL, then resnet.py:388 `ret + feat`),

@@ -64,7 +64,22 @@ if __name__ == "__main__":
                     ops.forward_nhwc(spec, ref, src, cam, res_bias=bias if wb else None, want_res_base=wb)
                 torch.cuda.synchronize()
                 print("  tile, res_base %s: %.3f ms" % (wb, (time.perf_counter() - t0) * 50), flush=True)
-            for ab, sg in ((0, 0), (1, 0), (2, 0), (4, 0), (7, 0)):
+            go = torch.randn_like(ref)
+            gr_t, gs_t = ops.backward_nhwc(spec, ref, src, cam, go, form="tile")
+            gr_g, gs_g = ops.backward_nhwc(spec, ref, src, cam, go, form="gather")
+            print("  bwd tile vs gather: grad_ref %.3e (scale %.3e) grad_src %.3e (scale %.3e)" % (
+                (gr_t - gr_g).abs().max().item(), gr_g.abs().max().item(), (gs_t - gs_g).abs().max().item(),
+                gs_g.abs().max().item()), flush=True)
+            for form in ("tile", "gather"):
+                for _ in range(2):
+                    ops.backward_nhwc(spec, ref, src, cam, go, form=form)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(5):
+                    ops.backward_nhwc(spec, ref, src, cam, go, form=form)
+                torch.cuda.synchronize()
+                print("  bwd %s: %.3f ms" % (form, (time.perf_counter() - t0) * 200), flush=True)
+            for ab, sg in ((0, 0),):
                 os.environ["ET_TILE_ABLATE"] = str(ab)
                 os.environ["ET_TILE_STAGGER"] = str(sg)
                 for _ in range(2):

@@ -261,9 +261,9 @@ def test_full_shape_pairs_vs_oracle(env, oracle_mod, shape, variant):
     g1, g2 = oracle_mod.backward(oracle_mod.LayerSpec(H, H, K), f1[:1].numpy(), f2[:1].numpy(),
                                  want["sample_locs"][:, :1], g.numpy())
     spec1 = ops.LayerSpec(H=H, W=H, K=K)
-    for use_ws in (True, False):
+    for form in ("tile", "gather", "atomic") if K <= 64 else ("gather", "atomic"):
         gr, gs = ops.backward_nhwc(spec1, ref[:1].contiguous(), src[:1].contiguous(), cam[:1].contiguous(),
-                                   ops.to_nhwc(g.cuda()), use_workspace=use_ws)
+                                   ops.to_nhwc(g.cuda()), form=form)
         for got, wantg in ((gr, g1), (gs, g2)):
             scale = np.abs(wantg).max()
             assert np.abs(got.permute(0, 3, 1, 2).cpu().numpy() - wantg).max() <= TOL_GRAD_REL * scale
@@ -425,8 +425,9 @@ def test_ragged_shapes_vs_oracle(env, oracle_mod, shape, variant):
     assert ((corr.cpu().numpy() != want["corr_pos"]).any(-1)).mean() <= 2e-2
     assert np.array_equal(ops.sample_locs(spec, cam.cuda()).cpu().numpy(), want["sample_locs"])
     g1, g2 = oracle_mod.backward(so, f1.numpy(), f2.numpy(), want["sample_locs"], go.numpy())
-    for use_ws in (True, False):
-        gr, gs = ops.backward_nhwc(spec, ref, src, cam.cuda(), ops.to_nhwc(go.cuda()), use_workspace=use_ws)
+    forms = ["gather", "atomic"] + (["tile"] if C == 256 and K <= 64 else [])
+    for form in forms:
+        gr, gs = ops.backward_nhwc(spec, ref, src, cam.cuda(), ops.to_nhwc(go.cuda()), form=form)
         for got, wantg in ((gr, g1), (gs, g2)):
             scale = max(np.abs(wantg).max(), 1e-6)
             assert np.abs(got.permute(0, 3, 1, 2).cpu().numpy() - wantg).max() <= TOL_GRAD_REL * scale
@@ -474,3 +475,31 @@ def test_tile_path_statistics_and_split(env):
     o_pp, a_pp, _ = ops.forward_nhwc(ops.LayerSpec(H=H, W=W, K=16, variant=16384), r16, s16, cam16)
     for o, a in ((o_split, a_split), (o_full, a_full)):
         assert (o - o_pp).abs().max().item() <= TOL_OUT and (a - a_pp).abs().max().item() <= TOL_ATTN
+
+
+def test_tiled_backward_masks_and_split(env):
+    """The MFMA tile backward (C=256, K<=64): equals the bit-reproducible gather form to rounding for every
+    OTHER_GRAD mask, also when 64-row tiles force the pixel-group splitting (no group may run twice: d(feat_src)
+    is accumulated with atomics)."""
+    _lib, camera, ops = env
+    for (H, K, variant) in ((16, 16, 0), (16, 16, 32768), (24, 33, 0)):
+        P1, P2 = _full_inputs(1, 4, H, 256, H * 4, seed=31)[:2]
+        g = torch.Generator().manual_seed(H + K)
+        ref = torch.randn(4, H, H, 256, generator=g).relu().cuda()
+        src = torch.randn(4, H, H, 256, generator=g).relu().cuda()
+        go = torch.randn(4, H, H, 256, generator=g).cuda()
+        ref[0, 3, 5] = 0                                     # an all-masked pixel
+        cam = camera.pair_algebra(P1, P2).cuda()
+        for mask in (3, 1, 2, 0):
+            spec = ops.LayerSpec(H=H, W=H, K=K, variant=variant, src_grad_mask=mask)
+            gr_t, gs_t = ops.backward_nhwc(spec, ref, src, cam, go, form="tile")
+            gr_g, gs_g = ops.backward_nhwc(spec, ref, src, cam, go, form="gather")
+            for got, want in ((gr_t, gr_g), (gs_t, gs_g)):
+                scale = max(want.abs().max().item(), 1e-6)
+                assert (got - want).abs().max().item() <= TOL_GRAD_REL * scale, (H, K, variant, mask)
+            if mask == 0:
+                assert gs_t.abs().max().item() == 0
+    with pytest.raises(_lib.EpipolarAmdError):               # outside the tile path: loud, no silent fallback
+        ops.backward_nhwc(ops.LayerSpec(H=8, W=8, K=8), torch.zeros(1, 8, 8, 32, device="cuda"),
+                          torch.zeros(1, 8, 8, 32, device="cuda"), torch.zeros(1, 27, device="cuda"),
+                          torch.zeros(1, 8, 8, 32, device="cuda"), form="tile")
