@@ -606,6 +606,7 @@ int et_epipolar_backward_tiled(const EtLayerDesc *desc, const float *xs, const f
     p.total_blocks = (int)total;
     tp.hw_words = (HW + 31) / 32;
     tp.rows_cap = tile_rows_cap(desc);
+    { const char *ab = getenv("ET_BTILE_ABLATE"); tp.ablate = ab ? atoi(ab) : 0; }
     int *perm = reinterpret_cast<int *>((reinterpret_cast<uintptr_t>(workspace) + 255) & ~(uintptr_t)255);
     tp.perm = perm;
     hipError_t me = hipMemsetAsync(grad_src, 0, (size_t)desc->N * HW * desc->C * sizeof(float), st);

@@ -70,6 +70,17 @@ if __name__ == "__main__":
             print("  bwd tile vs gather: grad_ref %.3e (scale %.3e) grad_src %.3e (scale %.3e)" % (
                 (gr_t - gr_g).abs().max().item(), gr_g.abs().max().item(), (gs_t - gs_g).abs().max().item(),
                 gs_g.abs().max().item()), flush=True)
+            for ab in ():
+                os.environ["ET_BTILE_ABLATE"] = str(ab)
+                for _ in range(2):
+                    ops.backward_nhwc(spec, ref, src, cam, go, form="tile")
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(5):
+                    ops.backward_nhwc(spec, ref, src, cam, go, form="tile")
+                torch.cuda.synchronize()
+                print("  bwd tile ablate %d: %.3f ms" % (ab, (time.perf_counter() - t0) * 200), flush=True)
+            os.environ["ET_BTILE_ABLATE"] = "0"
             for form in ("tile", "gather"):
                 for _ in range(2):
                     ops.backward_nhwc(spec, ref, src, cam, go, form=form)
