@@ -5,10 +5,14 @@
 //   epipolar_geometry.h    bit-faithful float32 geometry (segment, sample set-up), host+device
 //   this file              shared device helpers (cross-lane reductions, buffer addressing),
 //                          host-side dispatch and the extern "C" entry points
-//   kernels_forward.inc    fused forward: one pixel per wave (epipolar_fwd_kernel) and four
+//   kernels_forward_tile.inc   C == 256 head, forward: reference pixels ordered by epipolar line, 32 per tile, two fp32
+//                          GEMMs per tile on the matrix cores with the resampling / soft-max between them
+//   kernels_forward.inc    fused forward, any shape: one pixel per wave (epipolar_fwd_kernel) and four
 //                          pixels per wave in lockstep (epipolar_fwd_multi_kernel)
-//   kernels_backward.inc   backward: coefficient emission + scan / bucket / ordered gather
-//                          (no float atomics), and the float-atomic scatter fallback
+//   kernels_backward_tile.inc  C == 256 head, backward in the same tile form (five GEMMs per tile, d(feat_src)
+//                          accumulated across tiles with float atomics)
+//   kernels_backward.inc   backward, any shape: coefficient emission + scan / bucket / ordered gather
+//                          (no float atomics, bit-reproducible), and the float-atomic scatter fallback
 //   kernels_misc.inc       sample_locs, residual epilogue, NCHW <-> NHWC
 //
 // Common ideas:
