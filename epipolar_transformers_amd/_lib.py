@@ -68,6 +68,7 @@ _SIGNATURES = {
     "et_nchw_to_nhwc": (ctypes.c_int, [ctypes.c_int32] * 4 + [_P, _P, _P]),
     "et_nhwc_to_nchw": (ctypes.c_int, [ctypes.c_int32] * 4 + [_P, _P, _P]),
     "et_debug_tile_stats": (ctypes.c_int, [_P]),
+    "et_debug_tile_ablate": (ctypes.c_int, [ctypes.c_int32, ctypes.c_int32]),
     "et_debug_host_sample_setup": (ctypes.c_int, [_D, _P, _P, _P, _P, ctypes.c_int32, ctypes.c_int32, _P, _P, _P]),
 }
 

@@ -30,7 +30,6 @@
 
 #include <cstdarg>
 #include <cstdio>
-#include <cstdlib>
 #include <cstdint>
 #include <cstring>
 #include <type_traits>
@@ -465,7 +464,8 @@ int et_epipolar_forward(const EtLayerDesc *desc, const float *xs, const float *y
 // The MFMA tile path applies to the 256-channel head when one reference pixel alone can never
 // overflow the tile's row array: a pixel's K samples touch at most 4K source pixels, and a line
 // through a W x H map at most 4 per column (or per row, whichever way it runs), i.e. 4 max(W, H).
-static int *g_tile_stats = nullptr;  // tuning hook, see et_debug_tile_stats
+static int *g_tile_stats = nullptr;  // tuning hooks, see et_debug_tile_stats / et_debug_tile_ablate
+static int g_tile_ablate_fwd = 0, g_tile_ablate_bwd = 0;
 
 // rows per tile the kernel is instantiated with: 256 up to 64 x 64 maps, 384 beyond (longer lines)
 static int tile_rows(const EtLayerDesc *d) { return (d->W > 64 || d->H > 64) ? kTileRowsLarge : kTileRowsSmall; }
@@ -484,6 +484,13 @@ static bool tile_eligible(const EtLayerDesc *d)
 int et_debug_tile_stats(int32_t *device_buffer)
 {
     g_tile_stats = device_buffer;
+    return 0;
+}
+
+int et_debug_tile_ablate(int32_t forward_bits, int32_t backward_bits)
+{
+    g_tile_ablate_fwd = forward_bits;
+    g_tile_ablate_bwd = backward_bits;
     return 0;
 }
 
@@ -527,7 +534,7 @@ int et_epipolar_forward_tiled(const EtLayerDesc *desc, const float *xs, const fl
     p.total_blocks = (int)total;
     tp.hw_words = (HW + 31) / 32;
     tp.stats = g_tile_stats;
-    { const char *ab = getenv("ET_TILE_ABLATE"); tp.ablate = ab ? atoi(ab) : 0; }
+    tp.ablate = g_tile_ablate_fwd;
     tp.rows_cap = tile_rows_cap(desc);
     int *perm = reinterpret_cast<int *>((reinterpret_cast<uintptr_t>(workspace) + 255) & ~(uintptr_t)255);
     tp.perm = perm;
@@ -610,7 +617,7 @@ int et_epipolar_backward_tiled(const EtLayerDesc *desc, const float *xs, const f
     p.total_blocks = (int)total;
     tp.hw_words = (HW + 31) / 32;
     tp.rows_cap = tile_rows_cap(desc);
-    { const char *ab = getenv("ET_BTILE_ABLATE"); tp.ablate = ab ? atoi(ab) : 0; }
+    tp.ablate = g_tile_ablate_bwd;
     int *perm = reinterpret_cast<int *>((reinterpret_cast<uintptr_t>(workspace) + 255) & ~(uintptr_t)255);
     tp.perm = perm;
     hipError_t me = hipMemsetAsync(grad_src, 0, (size_t)desc->N * HW * desc->C * sizeof(float), st);

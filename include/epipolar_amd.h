@@ -187,6 +187,12 @@ int et_debug_host_sample_setup(const EtLayerDesc *desc, const float *xs, const f
  * the size of the tile's source-row set and the number of groups it had to be split into. */
 int et_debug_tile_stats(int32_t *device_buffer);
 
+/* Tuning hook (not thread-safe, leave 0 in production; WRONG RESULTS by construction): phases of the tile
+ * kernels to skip, for timing ablations (scripts/tile_check.py).  Forward bits: 1 first GEMM, 2 second GEMM,
+ * 4 soft-max phase, 16 whole tile kernel, 32 ordering kernel, 128 alternate tiles skip MFMA / soft-max,
+ * (n << 8) leave after set-up stage n.  Backward bits: 1 grad_src atomics, 2 transposed GEMMs, 4 B-row phases. */
+int et_debug_tile_ablate(int32_t forward_bits, int32_t backward_bits);
+
 #ifdef __cplusplus
 }
 #endif
