@@ -142,3 +142,28 @@ def test_layerspec_constants_match_reference_constructor():
         warnings.simplefilter("ignore")
         ref = torch.range(0, 1, 1.0 / 63)
     assert torch.equal(ref, spec.steps)
+
+
+def test_tile_path_eligibility_is_decided_on_the_host(lib):
+    """et_epipolar_forward_workspace_bytes / et_epipolar_backward_tiled_workspace_bytes run on the host: they say
+    which shapes take the MFMA tile kernels (C == 256, H*W <= 16384, one pixel's rows 4*min(K, max(W,H)) within the
+    256- or 384-row tile array; the backward also needs K <= 64) and size the per-pair pixel-order scratch."""
+    import ctypes
+
+    from epipolar_transformers_amd import ops
+
+    def sizes(H, W, K, C, N=3, variant=0):
+        d = ops.LayerSpec(H=H, W=W, K=K, variant=variant).desc(N, C)
+        return (int(lib.et_epipolar_forward_workspace_bytes(ctypes.byref(d))),
+                int(lib.et_epipolar_backward_tiled_workspace_bytes(ctypes.byref(d))))
+
+    fwd, bwd = sizes(64, 64, 64, 256)                       # configs[1]
+    assert fwd == bwd == 3 * 128 * 32 * 4 + 256
+    assert sizes(96, 96, 64, 256)[0] == 3 * 288 * 32 * 4 + 256      # config 4: 384-row tiles
+    assert sizes(10, 10, 16, 256)[0] == 3 * 4 * 32 * 4 + 256        # 100 pixels -> 4 padded tiles
+    assert sizes(64, 64, 64, 128) == (0, 0)                 # other channel counts: per-pixel kernels
+    assert sizes(128, 128, 128, 256) == (0, 0)              # config 5: 512 rows per pixel do not fit a tile
+    assert sizes(129, 128, 16, 256) == (0, 0)               # more than 16384 pixels per pair
+    f, b = sizes(32, 32, 128, 256)
+    assert f > 0 and b == 0                                 # K > 64: tiled forward only
+    assert sizes(16, 16, 16, 256, variant=32768)[0] > 0 and sizes(64, 64, 64, 256, variant=32768) == (0, 0)
