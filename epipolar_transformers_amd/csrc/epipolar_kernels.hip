@@ -467,8 +467,20 @@ int et_epipolar_forward(const EtLayerDesc *desc, const float *xs, const float *y
 static int *g_tile_stats = nullptr;  // tuning hooks, see et_debug_tile_stats / et_debug_tile_ablate
 static int g_tile_ablate_fwd = 0, g_tile_ablate_bwd = 0;
 
-// rows per tile the kernel is instantiated with: 256 up to 64 x 64 maps, 384 beyond (longer lines)
-static int tile_rows(const EtLayerDesc *d) { return (d->W > 64 || d->H > 64) ? kTileRowsLarge : kTileRowsSmall; }
+// one pixel's K samples touch at most 4K source pixels, and a line through a W x H map at most 4 per column (or per
+// row, whichever way it runs), i.e. 4 max(W, H)
+static int tile_rows_per_pixel(const EtLayerDesc *d)
+{
+    const int longest = d->W > d->H ? d->W : d->H;
+    return (d->K < longest) ? 4 * d->K : 4 * longest;
+}
+// rows per tile the kernel is instantiated with: 256 up to 64 x 64 maps, 384 beyond (longer lines), 512 when a
+// single pixel may need more than that
+static int tile_rows(const EtLayerDesc *d)
+{
+    if (tile_rows_per_pixel(d) > kTileRowsLarge) return kTileRowsHuge;
+    return (d->W > 64 || d->H > 64) ? kTileRowsLarge : kTileRowsSmall;
+}
 static int tile_rows_cap(const EtLayerDesc *d) { return (d->variant & ET_VARIANT_TILE_SPLIT) ? 64 : tile_rows(d); }
 
 static bool tile_eligible(const EtLayerDesc *d)
@@ -476,9 +488,7 @@ static bool tile_eligible(const EtLayerDesc *d)
     if (d->C != 256 || d->K > 256) return false;
     const long long hw = (long long)d->H * d->W;
     if (hw > 16384) return false;  // bitonic sort of one pair's pixels lives in LDS
-    const int longest = d->W > d->H ? d->W : d->H;
-    const int per_pixel = (d->K < longest) ? 4 * d->K : 4 * longest;
-    return per_pixel <= tile_rows_cap(d);
+    return tile_rows_per_pixel(d) <= tile_rows_cap(d);
 }
 
 int et_debug_tile_stats(int32_t *device_buffer)
@@ -570,10 +580,13 @@ int et_epipolar_forward_tiled(const EtLayerDesc *desc, const float *xs, const fl
         if (kpl == 1) ET_TILE(1, kTileRowsSmall);
         else if (kpl == 2) ET_TILE(2, kTileRowsSmall);
         else ET_TILE(4, kTileRowsSmall);
-    } else {
+    } else if (rows == kTileRowsLarge) {
         if (kpl == 1) ET_TILE(1, kTileRowsLarge);
         else if (kpl == 2) ET_TILE(2, kTileRowsLarge);
         else ET_TILE(4, kTileRowsLarge);
+    } else {
+        if (kpl == 2) ET_TILE(2, kTileRowsHuge);   // (512 rows per pixel need K > 96)
+        else ET_TILE(4, kTileRowsHuge);
     }
 #undef ET_TILE
     return check_launch("et_epipolar_forward_tiled");

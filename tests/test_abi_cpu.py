@@ -147,7 +147,7 @@ def test_layerspec_constants_match_reference_constructor():
 def test_tile_path_eligibility_is_decided_on_the_host(lib):
     """et_epipolar_forward_workspace_bytes / et_epipolar_backward_tiled_workspace_bytes run on the host: they say
     which shapes take the MFMA tile kernels (C == 256, H*W <= 16384, one pixel's rows 4*min(K, max(W,H)) within the
-    256- or 384-row tile array; the backward also needs K <= 64) and size the per-pair pixel-order scratch."""
+    256-, 384- or 512-row tile array; the backward also needs K <= 64) and size the per-pair pixel-order scratch."""
     import ctypes
 
     from epipolar_transformers_amd import ops
@@ -162,7 +162,8 @@ def test_tile_path_eligibility_is_decided_on_the_host(lib):
     assert sizes(96, 96, 64, 256)[0] == 3 * 288 * 32 * 4 + 256      # config 4: 384-row tiles
     assert sizes(10, 10, 16, 256)[0] == 3 * 4 * 32 * 4 + 256        # 100 pixels -> 4 padded tiles
     assert sizes(64, 64, 64, 128) == (0, 0)                 # other channel counts: per-pixel kernels
-    assert sizes(128, 128, 128, 256) == (0, 0)              # config 5: 512 rows per pixel do not fit a tile
+    f5, b5 = sizes(128, 128, 128, 256)                      # config 5: 512-row tiles, forward only (K > 64)
+    assert f5 == 3 * 512 * 32 * 4 + 256 and b5 == 0
     assert sizes(129, 128, 16, 256) == (0, 0)               # more than 16384 pixels per pair
     f, b = sizes(32, 32, 128, 256)
     assert f > 0 and b == 0                                 # K > 64: tiled forward only
