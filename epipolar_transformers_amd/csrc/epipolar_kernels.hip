@@ -565,7 +565,7 @@ int et_epipolar_forward_tiled(const EtLayerDesc *desc, const float *xs, const fl
     // 2. one block per tile
     const int kpl = (desc->K + 63) / 64;
     const int rows = tile_rows(desc);
-    const size_t lds = (size_t)(kTilePix * (rows + 1) + rows + kTilePix + 4 + kTilePix * 4) * 4 +
+    const size_t lds = (size_t)(tile_array_floats(rows) + rows + kTilePix + 4 + kTilePix * 4) * 4 +
                        (size_t)tp.hw_words * 8 + (kpl == 1 ? (size_t)kTilePix * kWave * 8 : 0);
 #define ET_TILE(KK, RR)                                                                                          \
     do {                                                                                                         \
@@ -647,7 +647,7 @@ int et_epipolar_backward_tiled(const EtLayerDesc *desc, const float *xs, const f
                        tp.tiles_per_pair * kTilePix, perm);
     if (int e = check_launch("et_epipolar_backward_tiled(order)")) return e;
     const int rows = tile_rows(desc);
-    const size_t lds = (size_t)(kTilePix * (rows + 1) + rows + kTilePix + 4 + kTilePix * 4) * 4 +
+    const size_t lds = (size_t)(tile_array_floats(rows) + rows + kTilePix + 4 + kTilePix * 4) * 4 +
                        (size_t)tp.hw_words * 8 + (size_t)kTilePix * kWave * 8;
 #define ET_BTILE(RR)                                                                                            \
     do {                                                                                                        \
