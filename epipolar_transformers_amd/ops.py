@@ -168,8 +168,10 @@ _workspaces = {}
 
 
 def _workspace(device, nbytes: int, tag: str = "bwd") -> torch.Tensor:
-    """Scratch for the gather-form backward, grown on demand and kept per device (288 GB of HBM: a few GB
-    of scratch is cheap; all use is stream-ordered on the caller's stream)."""
+    """Device scratch the library asks for (it allocates nothing itself): the pixel order of the tile kernels
+    (tag "fwd", 2 MB at Config 2) and the coefficient entries of the gather-form backward (tag "bwd", 3.8 GB at
+    Config 2 -- sized for 288 GB of HBM).  Grown on demand, kept per device; all use is stream-ordered on the
+    caller's stream."""
     key = (str(device), tag)
     buf = _workspaces.get(key)
     if buf is None or buf.numel() < nbytes:
@@ -239,7 +241,9 @@ class EpipolarAttend(torch.autograd.Function):
     samples of f_src on the pixel's epipolar segment (epipolar.py:188-247).
     Inputs/outputs are logical NCHW; attn and corr_pos are returned without
     gradient (the reference never back-propagates through them in the
-    configurations of BASELINE.json)."""
+    configurations of BASELINE.json).  The backward takes backward_nhwc's default form: the MFMA tile kernel for
+    the 256-channel head (float atomics across tiles, reproducible to rounding), the bit-reproducible gather form
+    otherwise or when the spec's variant carries ET_VARIANT_NO_TILE."""
 
     @staticmethod
     def forward(ctx, feat_ref, feat_src, cam, spec: LayerSpec):
