@@ -29,7 +29,10 @@ ET_VARIANT_BWD_ATOMIC = 4096
 ET_VARIANT_BWD_UNSORTED = 8192
 ET_VARIANT_NO_TILE = 16384
 ET_VARIANT_TILE_SPLIT = 32768
-ET_ABI_VERSION = 5
+ET_VARIANT_TILE_CLASSIC = 65536
+ET_VARIANT_WS_NV4 = 131072
+ET_VARIANT_WS_SETPRIO = 262144
+ET_ABI_VERSION = 6
 
 
 class EpipolarAmdError(RuntimeError):
@@ -59,6 +62,7 @@ _SIGNATURES = {
     "et_sample_locs": (ctypes.c_int, [_D, _P, _P, _P, _P, _P, _P]),
     "et_epipolar_forward": (ctypes.c_int, [_D, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "et_epipolar_forward_workspace_bytes": (ctypes.c_size_t, [_D]),
+    "et_epipolar_forward_workspace_stats_offset": (ctypes.c_size_t, [_D]),
     "et_epipolar_forward_tiled": (ctypes.c_int, [_D] + [_P] * 12 + [ctypes.c_size_t, _P]),
     "et_epipolar_backward_tiled_workspace_bytes": (ctypes.c_size_t, [_D]),
     "et_epipolar_backward_tiled": (ctypes.c_int, [_D, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, ctypes.c_size_t, _P]),
@@ -67,8 +71,6 @@ _SIGNATURES = {
     "et_residual_epilogue": (ctypes.c_int, [ctypes.c_int64, ctypes.c_int32, _P, _P, _P, _P, _P, _P, _P, _P]),
     "et_nchw_to_nhwc": (ctypes.c_int, [ctypes.c_int32] * 4 + [_P, _P, _P]),
     "et_nhwc_to_nchw": (ctypes.c_int, [ctypes.c_int32] * 4 + [_P, _P, _P]),
-    "et_debug_tile_stats": (ctypes.c_int, [_P]),
-    "et_debug_tile_ablate": (ctypes.c_int, [ctypes.c_int32, ctypes.c_int32]),
     "et_debug_host_sample_setup": (ctypes.c_int, [_D, _P, _P, _P, _P, ctypes.c_int32, ctypes.c_int32, _P, _P, _P]),
 }
 

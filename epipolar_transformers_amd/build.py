@@ -16,13 +16,23 @@ import sys
 
 PKG = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(PKG)
-SRC = [os.path.join(PKG, "csrc", "epipolar_kernels.hip")]
-DEPS = SRC + [os.path.join(PKG, "csrc", f) for f in ("epipolar_geometry.h", "kernels_forward.inc",
-                                                      "kernels_forward_tile.inc", "kernels_backward.inc", "kernels_backward_tile.inc",
-                                                      "kernels_misc.inc")] + \
-    [os.path.join(ROOT, "include", "epipolar_amd.h")]
+CSRC = os.path.join(PKG, "csrc")
+COMMON = ["et_common.h", "epipolar_geometry.h", os.path.join(ROOT, "include", "epipolar_amd.h")]
+# translation unit -> the files it includes besides COMMON
+UNITS = {
+    "et_forward.hip": ["kernels_sample_table.inc", "kernels_forward.inc"],
+    "et_forward_tile.hip": ["kernels_forward_tile.inc", "kernels_forward_tile_ws.inc", "et_tile_host.h"],
+    "et_backward.hip": ["kernels_sample_table.inc", "kernels_backward.inc"],
+    "et_backward_tile.hip": ["kernels_forward_tile.inc", "kernels_backward_tile.inc", "et_tile_host.h"],
+    "et_misc.hip": ["kernels_misc.inc"],
+}
 LIB = os.path.join(PKG, "lib", "libepipolar_amd.so")
+OBJ = os.path.join(PKG, "lib", "obj")
 ARCH = "gfx950"
+
+
+def _path(f):
+    return f if os.path.isabs(f) else os.path.join(CSRC, f)
 
 
 def hipcc() -> str:
@@ -33,28 +43,56 @@ def hipcc() -> str:
 
 
 def flags():
-    return ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
-            "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(PKG, "csrc")]
+    return ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC",
+            "-I" + os.path.join(ROOT, "include"), "-I" + CSRC]
+
+
+def _obj(unit):
+    return os.path.join(OBJ, os.path.splitext(unit)[0] + ".o")
+
+
+def _stale(unit) -> bool:
+    o = _obj(unit)
+    if not os.path.exists(o):
+        return True
+    t = os.path.getmtime(o)
+    return any(os.path.getmtime(_path(d)) > t for d in [unit] + UNITS[unit] + COMMON)
 
 
 def needs_build() -> bool:
-    if not os.path.exists(LIB):
-        return True
-    t = os.path.getmtime(LIB)
-    return any(os.path.getmtime(d) > t for d in DEPS)
+    return not os.path.exists(LIB) or any(_stale(u) for u in UNITS) or \
+        any(os.path.getmtime(_obj(u)) > os.path.getmtime(LIB) for u in UNITS)
+
+
+def _compile(unit, report):
+    cmd = [hipcc()] + flags() + (["-Rpass-analysis=kernel-resource-usage"] if report else []) + \
+        ["-c", "-o", _obj(unit), _path(unit)]
+    proc = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    return unit, proc.returncode, proc.stdout
 
 
 def build_library(force: bool = False, report: bool = False) -> str:
-    if not (force or report or needs_build()):
-        return LIB
-    os.makedirs(os.path.dirname(LIB), exist_ok=True)
-    cmd = [hipcc()] + flags() + (["-Rpass-analysis=kernel-resource-usage"] if report else []) + ["-o", LIB] + SRC
-    proc = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
-    if proc.returncode != 0:
-        sys.stderr.write(proc.stdout)
-        raise RuntimeError("hipcc failed (exit %d)" % proc.returncode)
+    """Compile the stale translation units in parallel (one hipcc per unit) and link them into LIB."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    os.makedirs(OBJ, exist_ok=True)
+    todo = [u for u in UNITS if force or report or _stale(u)]
+    logs = []
+    if todo:
+        with ThreadPoolExecutor(max_workers=min(len(todo), os.cpu_count() or 1)) as pool:
+            for unit, rc, out in pool.map(lambda u: _compile(u, report), todo):
+                if rc != 0:
+                    sys.stderr.write(out)
+                    raise RuntimeError("hipcc failed on %s (exit %d)" % (unit, rc))
+                logs.append(out)
+    if todo or not os.path.exists(LIB) or any(os.path.getmtime(_obj(u)) > os.path.getmtime(LIB) for u in UNITS):
+        cmd = [hipcc(), "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB] + [_obj(u) for u in UNITS]
+        proc = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        if proc.returncode != 0:
+            sys.stderr.write(proc.stdout)
+            raise RuntimeError("link failed (exit %d)" % proc.returncode)
     if report:
-        print(resource_table(proc.stdout))
+        print(resource_table("\n".join(logs)))
     return LIB
 
 

@@ -1,0 +1,83 @@
+// libepipolar_amd.so: the MFMA tile formulation of the backward (et_epipolar_backward_tiled).
+#include "et_common.h"
+
+namespace {
+#include "kernels_forward_tile.inc"   // tile_order_kernel and the tile helpers shared with the forward
+#include "kernels_backward_tile.inc"  // epipolar_bwd_tile_kernel
+}  // namespace
+#include "et_tile_host.h"
+
+extern "C" {
+
+size_t et_epipolar_backward_tiled_workspace_bytes(const EtLayerDesc *desc)
+{
+    if (validate(desc) || !tile_eligible(desc) || desc->K > 64) return 0;
+    return et_epipolar_forward_workspace_bytes(desc);
+}
+
+int et_epipolar_backward_tiled(const EtLayerDesc *desc, const float *xs, const float *ys, const float *steps,
+                               const float *cam, const float *feat_ref, const float *feat_src,
+                               const float *grad_out, float *grad_ref, float *grad_src, void *workspace,
+                               size_t workspace_bytes, void *stream)
+{
+    if (int e = validate(desc)) return e;
+    if (!xs || !ys || !steps || !cam || !feat_ref || !feat_src || !grad_out || !grad_ref || !grad_src)
+        return fail("et_epipolar_backward_tiled: NULL pointer");
+    const size_t need = et_epipolar_backward_tiled_workspace_bytes(desc);
+    if (need == 0)
+        return fail("et_epipolar_backward_tiled: needs C == 256, K <= 64, H*W <= 16384 and 4 min(K, max(W,H)) <= %d "
+                    "(got C=%d H=%d W=%d K=%d); use et_epipolar_backward", tile_rows_cap(desc), desc->C, desc->H,
+                    desc->W, desc->K);
+    if (!workspace || workspace_bytes < need)
+        return fail("et_epipolar_backward_tiled: workspace of %zu bytes is smaller than the %zu required",
+                    workspace ? workspace_bytes : (size_t)0, need);
+    hipStream_t st = (hipStream_t)stream;
+    const int HW = desc->H * desc->W;
+    BwdTileParams tp;
+    std::memset(&tp, 0, sizeof(tp));
+    BwdParams &p = tp.b;
+    p.d = *desc;
+    p.xs = xs; p.ys = ys; p.steps = steps; p.cam = cam;
+    p.fref = feat_ref; p.fsrc = feat_src; p.gout = grad_out;
+    p.gref = grad_ref; p.gsrc = grad_src;
+    tp.tiles_per_pair = (HW + kTilePix - 1) / kTilePix;
+    p.blocks_per_pair = tp.tiles_per_pair;
+    const long long total = (long long)tp.tiles_per_pair * desc->N;
+    if (total > 0x7fffffffLL) return fail("grid too large");
+    p.total_blocks = (int)total;
+    tp.hw_words = (HW + 31) / 32;
+    tp.rows_cap = tile_rows_cap(desc);
+    int *perm = reinterpret_cast<int *>((reinterpret_cast<uintptr_t>(workspace) + 255) & ~(uintptr_t)255);
+    tp.perm = perm;
+    hipError_t me = hipMemsetAsync(grad_src, 0, (size_t)desc->N * HW * desc->C * sizeof(float), st);
+    if (me != hipSuccess) return fail("hipMemsetAsync(grad_src): %s", hipGetErrorString(me));
+    int n2 = 64;
+    while (n2 < HW) n2 <<= 1;
+    const size_t lds_sort = (size_t)n2 * sizeof(unsigned long long);
+    if (lds_sort > 48 * 1024) {
+        hipError_t ae = hipFuncSetAttribute(reinterpret_cast<const void *>(tile_order_kernel),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_sort);
+        if (ae != hipSuccess) return fail("hipFuncSetAttribute(tile_order_kernel): %s", hipGetErrorString(ae));
+    }
+    hipLaunchKernelGGL(tile_order_kernel, dim3(desc->N), dim3(1024), lds_sort, st, *desc, xs, ys, cam, n2,
+                       tp.tiles_per_pair * kTilePix, perm, (int *)nullptr);
+    if (int e = check_launch("et_epipolar_backward_tiled(order)")) return e;
+    const int rows = tile_rows(desc);
+    const size_t lds = (size_t)(tile_array_floats(rows) + rows + kTilePix + 4 + kTilePix * 4) * 4 +
+                       (size_t)tp.hw_words * 8 + (size_t)kTilePix * kWave * 8;
+#define ET_BTILE(RR)                                                                                            \
+    do {                                                                                                        \
+        if (lds > 48 * 1024) {                                                                                  \
+            hipError_t ae = hipFuncSetAttribute(reinterpret_cast<const void *>(epipolar_bwd_tile_kernel<RR>),   \
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);          \
+            if (ae != hipSuccess) return fail("hipFuncSetAttribute(bwd tile kernel): %s", hipGetErrorString(ae)); \
+        }                                                                                                       \
+        hipLaunchKernelGGL((epipolar_bwd_tile_kernel<RR>), dim3((unsigned)total), dim3(256), lds, st, tp);      \
+    } while (0)
+    if (rows == kTileRowsSmall) ET_BTILE(kTileRowsSmall);
+    else ET_BTILE(kTileRowsLarge);
+#undef ET_BTILE
+    return check_launch("et_epipolar_backward_tiled");
+}
+
+}  // extern "C"

@@ -1,0 +1,66 @@
+// Host-side helpers shared by the two tile translation units (et_forward_tile.hip, et_backward_tile.hip).
+#pragma once
+namespace {
+// The MFMA tile path applies to the 256-channel head when one reference pixel alone can never
+// overflow the tile's row array: a pixel's K samples touch at most 4K source pixels, and a line
+// through a W x H map at most 4 per column (or per row, whichever way it runs), i.e. 4 max(W, H).
+// one pixel's K samples touch at most 4K source pixels, and a line through a W x H map at most 4 per column (or per
+// row, whichever way it runs), i.e. 4 max(W, H)
+int tile_rows_per_pixel(const EtLayerDesc *d)
+{
+    const int longest = d->W > d->H ? d->W : d->H;
+    return (d->K < longest) ? 4 * d->K : 4 * longest;
+}
+// rows per tile the kernel is instantiated with: 256 up to 64 x 64 maps, 384 beyond (longer lines), 512 when a
+// single pixel may need more than that
+int tile_rows(const EtLayerDesc *d)
+{
+    if (tile_rows_per_pixel(d) > kTileRowsLarge) return kTileRowsHuge;
+    return (d->W > 64 || d->H > 64) ? kTileRowsLarge : kTileRowsSmall;
+}
+int tile_rows_cap(const EtLayerDesc *d) { return (d->variant & ET_VARIANT_TILE_SPLIT) ? 64 : tile_rows(d); }
+
+bool tile_eligible(const EtLayerDesc *d)
+{
+    if (d->C != 256 || d->K > 256) return false;
+    const long long hw = (long long)d->H * d->W;
+    if (hw > 16384) return false;  // bitonic sort of one pair's pixels lives in LDS
+    return tile_rows_per_pixel(d) <= tile_rows_cap(d);
+}
+
+// the warp-specialised persistent kernel: lanes <-> samples (K <= 64), 256-row arrays
+bool tile_ws_eligible(const EtLayerDesc *d)
+{
+    return !(d->variant & ET_VARIANT_TILE_CLASSIC) && d->K <= 64 && tile_rows(d) == kTileRowsSmall;
+}
+
+// compute units of the current device (the persistent kernel launches one block per CU); cached per device
+int device_cus()
+{
+    int cached[64] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+    int v = __atomic_load_n(&cached[dev], __ATOMIC_RELAXED);
+    if (v == 0) {
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+        __atomic_store_n(&cached[dev], v, __ATOMIC_RELAXED);
+    }
+    return v;
+}
+
+// Workspace of the tile forward (all int32, base aligned up to 256 bytes):
+//   perm[tiles * 32] | overflow count (64 words) | overflow list[tiles] | stats[tiles]
+struct TileWorkspace {
+    int *perm, *ovf_count, *ovf_list, *stats;
+};
+size_t tile_workspace_words(size_t tiles) { return tiles * kTilePix + 64 + 2 * tiles; }
+TileWorkspace carve_tile_workspace(void *workspace, size_t tiles)
+{
+    TileWorkspace w;
+    w.perm = reinterpret_cast<int *>((reinterpret_cast<uintptr_t>(workspace) + 255) & ~(uintptr_t)255);
+    w.ovf_count = w.perm + tiles * kTilePix;
+    w.ovf_list = w.ovf_count + 64;
+    w.stats = w.ovf_list + tiles;
+    return w;
+}
+}  // namespace

@@ -120,10 +120,15 @@ def sample_locs(spec: LayerSpec, cam: torch.Tensor) -> torch.Tensor:
     return out
 
 
+_TILE_BITS = (_lib.ET_VARIANT_TILE_SPLIT | _lib.ET_VARIANT_TILE_CLASSIC | _lib.ET_VARIANT_WS_NV4 |
+              _lib.ET_VARIANT_WS_SETPRIO)      # variant bits that tune the tile path instead of leaving it
+
+
 def forward_nhwc(spec: LayerSpec, ref: torch.Tensor, src: torch.Tensor, cam: torch.Tensor,
-                 want_attn=True, want_corr=True, res_bias=None, want_res_base=False):
+                 want_attn=True, want_corr=True, res_bias=None, want_res_base=False, workspace=None):
     """ref/src: (N,H,W,C) contiguous.  Returns out (N,H,W,C), attn (N,K,H,W)|None, corr_pos (N,H,W,2)|None
-    [, res_base (N,H,W,C) = ref + res_bias when want_res_base]."""
+    [, res_base (N,H,W,C) = ref + res_bias when want_res_base].  `workspace`: a caller-owned uint8 tensor for the
+    tile path (see tile_workspace / tile_stats) instead of the cached per-(device, stream) one."""
     for t, nm in ((ref, "feat_ref"), (src, "feat_src"), (cam, "cam")):
         _require_gpu(t, nm)
     n, h, w, c = ref.shape
@@ -145,10 +150,12 @@ def forward_nhwc(spec: LayerSpec, ref: torch.Tensor, src: torch.Tensor, cam: tor
     # variant 0 (the library default) takes the MFMA tile formulation wherever it applies (C == 256 head);
     # any explicit variant bit selects the per-pixel kernels
     ws_bytes = int(lib.et_epipolar_forward_workspace_bytes(ctypes.byref(d))) \
-        if (d.variant & ~_lib.ET_VARIANT_TILE_SPLIT) == 0 else 0
+        if (d.variant & ~_TILE_BITS) == 0 else 0
     with torch.cuda.device(ref.device):
         if ws_bytes > 0:
-            ws = _workspace(ref.device, ws_bytes, "fwd")
+            ws = workspace if workspace is not None else _workspace(ref.device, ws_bytes, "fwd")
+            if ws.numel() < ws_bytes or ws.device != ref.device:
+                raise ValueError("workspace of %d bytes on %s: need %d on %s" % (ws.numel(), ws.device, ws_bytes, ref.device))
             _lib.check(lib.et_epipolar_forward_tiled(ctypes.byref(d), _ptr(xs), _ptr(ys), _ptr(steps), _ptr(cam),
                                                      _ptr(ref), _ptr(src), _ptr(out), _ptr(attn), _ptr(corr),
                                                      _ptr(res_bias), _ptr(base), _ptr(ws), ctypes.c_size_t(ws_bytes),
@@ -168,15 +175,41 @@ _workspaces = {}
 
 
 def _workspace(device, nbytes: int, tag: str = "bwd") -> torch.Tensor:
-    """Device scratch the library asks for (it allocates nothing itself): the pixel order of the tile kernels
-    (tag "fwd", 2 MB at Config 2) and the coefficient entries of the gather-form backward (tag "bwd", 3.8 GB at
-    Config 2 -- sized for 288 GB of HBM).  Grown on demand, kept per device; all use is stream-ordered on the
-    caller's stream."""
-    key = (str(device), tag)
+    """Device scratch the library asks for (it allocates nothing itself): the pixel order / overflow list / tile
+    statistics of the tile kernels (tag "fwd", 2.3 MB at Config 2) and the coefficient entries of the gather-form
+    backward (tag "bwd", 3.8 GB at Config 2 -- sized for 288 GB of HBM).  One buffer per (device, stream, tag), grown
+    on demand: all use is stream-ordered on the stream it is keyed by, so concurrent streams / DataParallel threads
+    never share one.  release_workspaces() drops them."""
+    dev = torch.device(device)
+    key = (dev.type, dev.index if dev.index is not None else torch.cuda.current_device(),
+           torch.cuda.current_stream(dev).cuda_stream, tag)
     buf = _workspaces.get(key)
     if buf is None or buf.numel() < nbytes:
         _workspaces[key] = buf = torch.empty(nbytes, dtype=torch.uint8, device=device)
     return buf
+
+
+def release_workspaces():
+    """Drop every cached scratch buffer (e.g. the 3.8 GB of the gather-form backward after a training phase)."""
+    _workspaces.clear()
+
+
+def tile_workspace(spec: LayerSpec, n: int, c: int, device) -> torch.Tensor:
+    """A caller-owned workspace for forward_nhwc(..., workspace=...) on the tile path (empty tensor if it does not
+    apply to this shape)."""
+    d = spec.desc(n, c)
+    return torch.zeros(int(_lib.load().et_epipolar_forward_workspace_bytes(ctypes.byref(d))), dtype=torch.uint8,
+                       device=device)
+
+
+def tile_stats(spec: LayerSpec, n: int, c: int, workspace: torch.Tensor) -> torch.Tensor:
+    """Per-tile statistics the tile forward leaves in its workspace: int32 (N * tiles_per_pair,),
+    U | groups << 16 (size of the tile's source-row set, number of pixel groups it was split into)."""
+    d = spec.desc(n, c)
+    off = int(_lib.load().et_epipolar_forward_workspace_stats_offset(ctypes.byref(d)))
+    tiles = n * ((spec.H * spec.W + 31) // 32)
+    base = (-workspace.data_ptr()) % 256                     # the library aligns the base up to 256 bytes
+    return workspace[base + off: base + off + 4 * tiles].view(torch.int32)
 
 
 _BWD_EXPLICIT = _lib.ET_VARIANT_BWD_ATOMIC | _lib.ET_VARIANT_BWD_UNSORTED | _lib.ET_VARIANT_NO_TILE

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define ET_ABI_VERSION 5
+#define ET_ABI_VERSION 6
 
 /* Static description of one layer call: the cfg keys the reference reads in
  * Epipolar.__init__ (epipolar.py:12-54) and at call time (epipolar.py:303-311,
@@ -78,6 +78,9 @@ typedef struct EtLayerDesc {
 #define ET_VARIANT_BWD_UNSORTED 8192 /* backward gather: sum in arrival order (faster, not bit-reproducible) */
 #define ET_VARIANT_NO_TILE 16384  /* host wrappers: do not route C == 256 calls to et_epipolar_forward_tiled */
 #define ET_VARIANT_TILE_SPLIT 32768 /* et_epipolar_forward_tiled, testing: 64-row tiles, so that tiles overflow and split */
+#define ET_VARIANT_TILE_CLASSIC 65536 /* et_epipolar_forward_tiled: the one-block-per-tile kernel instead of the warp-specialised persistent one */
+#define ET_VARIANT_WS_NV4 131072  /* warp-specialised kernel, tuning: 4 vector waves per block instead of 8 */
+#define ET_VARIANT_WS_SETPRIO 262144 /* warp-specialised kernel, tuning: s_setprio 1 on the matrix waves */
 #define ET_VARIANT_BASELINE 256    /* batches of 8, compiler-chosen registers, pixels 4w..4w+3 per wave   */
 #define ET_VARIANT_ABLATE_NO_LOADS 64  /* profiling only, WRONG RESULTS: no tap loads after the first sample */
 #define ET_VARIANT_ABLATE_ONE_ROW 128  /* profiling only, WRONG RESULTS: every tap load reads source row 0    */
@@ -113,13 +116,20 @@ int et_epipolar_forward(const EtLayerDesc *desc, const float *xs, const float *y
 /* The same operator in its MFMA tile formulation (C == 256 head): reference pixels are ordered by
  * their epipolar line, 32 neighbouring lines form a tile, and the channel-long work of the tile runs
  * as two fp32 GEMMs on the matrix cores against the union of the source rows the tile touches
- * (each source row is fetched per tile, not per pixel).  Same arguments and results as
+ * (each source row is fetched per tile, not per pixel).  For K <= 64 on maps up to 64 x 64 the tiles
+ * are walked by one persistent block per compute unit whose waves are specialised (matrix waves run
+ * the two GEMMs of consecutive tiles back to back, vector waves do the geometry / soft-max work of the
+ * neighbouring tiles meanwhile); other shapes run one block per tile.  Same arguments and results as
  * et_epipolar_forward (rounding differs at the 1e-6 level: the sums are re-associated), plus
- *   workspace : device scratch of at least et_epipolar_forward_workspace_bytes(desc) bytes
- *               (the per-pair pixel order).
+ *   workspace : device scratch of at least et_epipolar_forward_workspace_bytes(desc) bytes, 256-byte
+ *               aligned: the per-pair pixel order, the overflow-tile list and one int32 of statistics
+ *               per tile ( U | groups << 16 : size of the tile's source-row set, number of groups it
+ *               was split into) starting et_epipolar_forward_workspace_stats_offset(desc) bytes in --
+ *               readable by the caller after the call, in tile order (pair-major).
  * et_epipolar_forward_workspace_bytes returns 0 when the tile path does not apply to `desc`
  * (then et_epipolar_forward_tiled fails and et_epipolar_forward is the path to call). */
 size_t et_epipolar_forward_workspace_bytes(const EtLayerDesc *desc);
+size_t et_epipolar_forward_workspace_stats_offset(const EtLayerDesc *desc);
 int et_epipolar_forward_tiled(const EtLayerDesc *desc, const float *xs, const float *ys, const float *steps,
                               const float *cam, const float *feat_ref, const float *feat_src, float *out,
                               float *attn, float *corr_pos, const float *res_bias, float *res_base,
@@ -181,17 +191,6 @@ int et_nhwc_to_nchw(int32_t N, int32_t C, int32_t H, int32_t W, const float *src
 int et_debug_host_sample_setup(const EtLayerDesc *desc, const float *xs, const float *ys,
                                const float *steps, const float *cam, int32_t h, int32_t w,
                                int32_t *taps, float *weights, float *locs);
-
-/* Tuning hook (not thread-safe, leave NULL in production): while a DEVICE buffer of one int32 per
- * tile (N * ceil(H*W/32)) is registered, et_epipolar_forward_tiled records  U | groups << 16  per tile:
- * the size of the tile's source-row set and the number of groups it had to be split into. */
-int et_debug_tile_stats(int32_t *device_buffer);
-
-/* Tuning hook (not thread-safe, leave 0 in production; WRONG RESULTS by construction): phases of the tile
- * kernels to skip, for timing ablations (scripts/tile_check.py).  Forward bits: 1 first GEMM, 2 second GEMM,
- * 4 soft-max phase, 16 whole tile kernel, 32 ordering kernel, 128 alternate tiles skip MFMA / soft-max,
- * (n << 8) leave after set-up stage n.  Backward bits: 1 grad_src atomics, 2 transposed GEMMs, 4 B-row phases. */
-int et_debug_tile_ablate(int32_t forward_bits, int32_t backward_bits);
 
 #ifdef __cplusplus
 }

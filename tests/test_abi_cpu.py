@@ -157,13 +157,18 @@ def test_tile_path_eligibility_is_decided_on_the_host(lib):
         return (int(lib.et_epipolar_forward_workspace_bytes(ctypes.byref(d))),
                 int(lib.et_epipolar_backward_tiled_workspace_bytes(ctypes.byref(d))))
 
+    def ws_bytes(tiles):        # pixel order (32 per tile) | overflow counter (64 words) | overflow list | statistics
+        return (tiles * 32 + 64 + 2 * tiles) * 4 + 256
+
     fwd, bwd = sizes(64, 64, 64, 256)                       # configs[1]
-    assert fwd == bwd == 3 * 128 * 32 * 4 + 256
-    assert sizes(96, 96, 64, 256)[0] == 3 * 288 * 32 * 4 + 256      # config 4: 384-row tiles
-    assert sizes(10, 10, 16, 256)[0] == 3 * 4 * 32 * 4 + 256        # 100 pixels -> 4 padded tiles
+    assert fwd == bwd == ws_bytes(3 * 128)
+    assert sizes(96, 96, 64, 256)[0] == ws_bytes(3 * 288)           # config 4: 384-row tiles
+    assert sizes(10, 10, 16, 256)[0] == ws_bytes(3 * 4)             # 100 pixels -> 4 padded tiles
+    d = ops.LayerSpec(H=64, W=64, K=64).desc(3, 256)
+    assert int(lib.et_epipolar_forward_workspace_stats_offset(ctypes.byref(d))) == (3 * 128 * 32 + 64 + 3 * 128) * 4
     assert sizes(64, 64, 64, 128) == (0, 0)                 # other channel counts: per-pixel kernels
     f5, b5 = sizes(128, 128, 128, 256)                      # config 5: 512-row tiles, forward only (K > 64)
-    assert f5 == 3 * 512 * 32 * 4 + 256 and b5 == 0
+    assert f5 == ws_bytes(3 * 512) and b5 == 0
     assert sizes(129, 128, 16, 256) == (0, 0)               # more than 16384 pixels per pair
     f, b = sizes(32, 32, 128, 256)
     assert f > 0 and b == 0                                 # K > 64: tiled forward only

@@ -440,25 +440,20 @@ def test_tile_path_statistics_and_split(env):
     """The MFMA tile path: epipolar-line ordering keeps the row set of a 32-pixel tile small (no tile of the
     headline geometry overflows 256 rows), and the 64-row test variant really exercises the group splitting
     while giving the same results."""
-    import ctypes
-
     _lib, camera, ops = env
-    lib = _lib.load()
     P1, P2, f1, f2 = _full_inputs(1, 4, 64, 256, 256, seed=13)
     cam = camera.pair_algebra(P1, P2).cuda()
     ref, src = ops.to_nhwc(f1.cuda()), ops.to_nhwc(f2.cuda())
     n = P1.shape[0]
-    stats = torch.zeros(n * 128, dtype=torch.int32, device="cuda")
-    lib.et_debug_tile_stats(ctypes.c_void_p(stats.data_ptr()))
-    try:
-        out, attn, corr = ops.forward_nhwc(ops.LayerSpec(H=64, W=64, K=64), ref, src, cam)
+    for variant in (0, _lib.ET_VARIANT_TILE_CLASSIC):        # warp-specialised persistent kernel, one block per tile
+        spec = ops.LayerSpec(H=64, W=64, K=64, variant=variant)
+        ws = ops.tile_workspace(spec, n, 256, "cuda")
+        out, attn, corr = ops.forward_nhwc(spec, ref, src, cam, workspace=ws)
         torch.cuda.synchronize()
-    finally:
-        lib.et_debug_tile_stats(None)
-    st = stats.cpu().numpy()
-    rows, groups = st & 0xFFFF, st >> 16
-    assert groups.max() == 1 and rows.max() <= 256
-    assert rows[rows > 0].mean() < 200            # a pixel alone touches ~130 rows: the tiles are tight
+        st = ops.tile_stats(spec, n, 256, ws).cpu().numpy()
+        rows, groups = st & 0xFFFF, st >> 16
+        assert groups.min() == 1 and groups.max() == 1 and rows.max() <= 256
+        assert rows[rows > 0].mean() < 200            # a pixel alone touches ~130 rows: the tiles are tight
     # small map, 64-row tiles: most tiles must split
     H = W = 16
     P1, P2 = _full_inputs(1, 4, H, 256, 64, seed=14)[:2]
@@ -466,18 +461,19 @@ def test_tile_path_statistics_and_split(env):
     r16 = torch.randn(4, H, W, 256, generator=g).relu().cuda()
     s16 = torch.randn(4, H, W, 256, generator=g).relu().cuda()
     cam16 = camera.pair_algebra(P1, P2).cuda()
-    stats = torch.zeros(4 * 8, dtype=torch.int32, device="cuda")
-    lib.et_debug_tile_stats(ctypes.c_void_p(stats.data_ptr()))
-    try:
-        o_split, a_split, _ = ops.forward_nhwc(ops.LayerSpec(H=H, W=W, K=16, variant=32768), r16, s16, cam16)
-        torch.cuda.synchronize()
-    finally:
-        lib.et_debug_tile_stats(None)
-    assert (stats.cpu().numpy() >> 16).max() > 1, "no tile was split: the test does not cover the group loop"
-    o_full, a_full, _ = ops.forward_nhwc(ops.LayerSpec(H=H, W=W, K=16), r16, s16, cam16)
     o_pp, a_pp, _ = ops.forward_nhwc(ops.LayerSpec(H=H, W=W, K=16, variant=16384), r16, s16, cam16)
-    for o, a in ((o_split, a_split), (o_full, a_full)):
-        assert (o - o_pp).abs().max().item() <= TOL_OUT and (a - a_pp).abs().max().item() <= TOL_ATTN
+    o_full, a_full, _ = ops.forward_nhwc(ops.LayerSpec(H=H, W=W, K=16), r16, s16, cam16)
+    assert (o_full - o_pp).abs().max().item() <= TOL_OUT and (a_full - a_pp).abs().max().item() <= TOL_ATTN
+    # 32768: the persistent kernel hands every overflowing tile to the list kernel, which splits it;
+    # 32768 | classic: the one-block-per-tile kernel splits in place
+    for variant in (_lib.ET_VARIANT_TILE_SPLIT, _lib.ET_VARIANT_TILE_SPLIT | _lib.ET_VARIANT_TILE_CLASSIC):
+        spec = ops.LayerSpec(H=H, W=W, K=16, variant=variant)
+        ws = ops.tile_workspace(spec, 4, 256, "cuda")
+        o_split, a_split, _ = ops.forward_nhwc(spec, r16, s16, cam16, workspace=ws)
+        torch.cuda.synchronize()
+        st = ops.tile_stats(spec, 4, 256, ws).cpu().numpy()
+        assert (st >> 16).min() >= 1 and (st >> 16).max() > 1, "no tile was split: the test does not cover the group loop"
+        assert (o_split - o_pp).abs().max().item() <= TOL_OUT and (a_split - a_pp).abs().max().item() <= TOL_ATTN
 
 
 def test_tiled_backward_masks_and_split(env):
