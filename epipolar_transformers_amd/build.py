@@ -44,7 +44,7 @@ def hipcc() -> str:
 
 def flags():
     return ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC",
-            "-I" + os.path.join(ROOT, "include"), "-I" + CSRC]
+            "-I" + os.path.join(ROOT, "include"), "-I" + CSRC] + os.environ.get("ET_EXTRA_HIPCC_FLAGS", "").split()
 
 
 def _obj(unit):

@@ -1,5 +1,6 @@
 // libepipolar_amd.so: the MFMA tile formulation of the forward (et_epipolar_forward_tiled).
 #include "et_common.h"
+#include <cstdlib>
 
 namespace {
 #include "kernels_forward_tile.inc"     // tile_order_kernel, epipolar_fwd_tile_kernel / _list_kernel
@@ -7,13 +8,22 @@ namespace {
 }  // namespace
 #include "et_tile_host.h"
 
+#ifdef ET_WS_PROFILE
+static long long *g_ws_prof = nullptr;   // profiling builds only (python -m epipolar_transformers_amd.build --profile)
+extern "C" int et_dev_ws_profile(long long *device_buffer)
+{
+    g_ws_prof = device_buffer;
+    return 0;
+}
+#endif
+
 extern "C" {
 
 size_t et_epipolar_forward_workspace_bytes(const EtLayerDesc *desc)
 {
     if (validate(desc) || !tile_eligible(desc)) return 0;
     const size_t tiles = (size_t)desc->N * (((size_t)desc->H * desc->W + kTilePix - 1) / kTilePix);
-    return tile_workspace_words(tiles) * sizeof(int) + 256u;
+    return tile_workspace_words(tiles, (size_t)desc->N) * sizeof(int) + 256u;
 }
 
 size_t et_epipolar_forward_workspace_stats_offset(const EtLayerDesc *desc)
@@ -56,7 +66,7 @@ int et_epipolar_forward_tiled(const EtLayerDesc *desc, const float *xs, const fl
     p.total_blocks = (int)total;
     tp.hw_words = (HW + 31) / 32;
     tp.rows_cap = tile_rows_cap(desc);
-    const TileWorkspace w = carve_tile_workspace(workspace, (size_t)total);
+    const TileWorkspace w = carve_tile_workspace(workspace, (size_t)total, (size_t)desc->N);
     tp.perm = w.perm;
     tp.stats = w.stats;
     tp.tile_list = w.ovf_list;
@@ -71,7 +81,7 @@ int et_epipolar_forward_tiled(const EtLayerDesc *desc, const float *xs, const fl
         if (ae != hipSuccess) return fail("hipFuncSetAttribute(tile_order_kernel): %s", hipGetErrorString(ae));
     }
     hipLaunchKernelGGL(tile_order_kernel, dim3(desc->N), dim3(1024), lds_sort, st, *desc, xs, ys, cam, n2,
-                       tp.tiles_per_pair * kTilePix, w.perm, w.ovf_count);
+                       tp.tiles_per_pair * kTilePix, w.perm, w.ovf_count, feat_ref, feat_src, w.scales, w.segs);
     if (int e = check_launch("et_epipolar_forward_tiled(order)")) return e;
     const int kpl = (desc->K + 63) / 64;
     const int rows = tile_rows(desc);
@@ -97,10 +107,19 @@ int et_epipolar_forward_tiled(const EtLayerDesc *desc, const float *xs, const fl
         wp.ovf_count = w.ovf_count;
         wp.ovf_list = w.ovf_list;
         wp.stats = w.stats;
+        wp.scales = w.scales;
+        wp.segs = w.segs;
         wp.setprio = (desc->variant & ET_VARIANT_WS_SETPRIO) ? 1 : 0;
+        wp.div_w_magic = (unsigned)((0x100000000ULL + (unsigned)desc->W - 1) / (unsigned)desc->W);
+#ifdef ET_WS_PROFILE
+        wp.prof = g_ws_prof;
+        if (const char *e = getenv("ET_WS_EXPERIMENT")) wp.setprio |= atoi(e);
+#else
+        wp.prof = nullptr;
+#endif
         const int cus = device_cus();
         const unsigned grid = (unsigned)(total < cus ? total : cus);
-        const size_t lds_ws = tile_ws_lds_bytes(kTileRowsSmall, tp.hw_words);
+        const size_t lds_ws = tile_ws_lds_bytes(kTileRowsSmall, tp.hw_words, desc->H, desc->W);
         if (desc->variant & ET_VARIANT_WS_NV4) {
             ET_SET_LDS((epipolar_fwd_tile_ws_kernel<kTileRowsSmall, 4>), lds_ws);
             hipLaunchKernelGGL((epipolar_fwd_tile_ws_kernel<kTileRowsSmall, 4>), dim3(grid), dim3((kWsMatrixWaves + 4) * kWave),

@@ -31,7 +31,7 @@ bool tile_eligible(const EtLayerDesc *d)
 // the warp-specialised persistent kernel: lanes <-> samples (K <= 64), 256-row arrays
 bool tile_ws_eligible(const EtLayerDesc *d)
 {
-    return !(d->variant & ET_VARIANT_TILE_CLASSIC) && d->K <= 64 && tile_rows(d) == kTileRowsSmall;
+    return !(d->variant & ET_VARIANT_TILE_CLASSIC) && d->K <= 64 && d->W >= 2 && tile_rows(d) == kTileRowsSmall;
 }
 
 // compute units of the current device (the persistent kernel launches one block per CU); cached per device
@@ -49,18 +49,23 @@ int device_cus()
 }
 
 // Workspace of the tile forward (all int32, base aligned up to 256 bytes):
-//   perm[tiles * 32] | overflow count (64 words) | overflow list[tiles] | stats[tiles]
+//   perm[tiles * 32] | overflow count (64 words) | overflow list[tiles] | stats[tiles] | scales[4 * N] (float) |
+//   segments[tiles * 32] (float4, 16-byte aligned)
 struct TileWorkspace {
     int *perm, *ovf_count, *ovf_list, *stats;
+    float *scales;
+    float4 *segs;
 };
-size_t tile_workspace_words(size_t tiles) { return tiles * kTilePix + 64 + 2 * tiles; }
-TileWorkspace carve_tile_workspace(void *workspace, size_t tiles)
+size_t tile_workspace_words(size_t tiles, size_t pairs) { return tiles * kTilePix + 64 + 2 * tiles + 4 * pairs + 4 + 4 * tiles * kTilePix; }
+TileWorkspace carve_tile_workspace(void *workspace, size_t tiles, size_t pairs)
 {
     TileWorkspace w;
     w.perm = reinterpret_cast<int *>((reinterpret_cast<uintptr_t>(workspace) + 255) & ~(uintptr_t)255);
     w.ovf_count = w.perm + tiles * kTilePix;
     w.ovf_list = w.ovf_count + 64;
     w.stats = w.ovf_list + tiles;
+    w.scales = reinterpret_cast<float *>(w.stats + tiles);
+    w.segs = reinterpret_cast<float4 *>((reinterpret_cast<uintptr_t>(w.scales + 4 * pairs) + 15) & ~(uintptr_t)15);
     return w;
 }
 }  // namespace

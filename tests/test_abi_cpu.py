@@ -157,8 +157,8 @@ def test_tile_path_eligibility_is_decided_on_the_host(lib):
         return (int(lib.et_epipolar_forward_workspace_bytes(ctypes.byref(d))),
                 int(lib.et_epipolar_backward_tiled_workspace_bytes(ctypes.byref(d))))
 
-    def ws_bytes(tiles):        # pixel order (32 per tile) | overflow counter (64 words) | overflow list | statistics
-        return (tiles * 32 + 64 + 2 * tiles) * 4 + 256
+    def ws_bytes(tiles, pairs=3):   # pixel order (32 per tile) | overflow counter (64 words) | overflow list | statistics | scales | segments
+        return (tiles * 32 + 64 + 2 * tiles + 4 * pairs + 4 + 4 * tiles * 32) * 4 + 256
 
     fwd, bwd = sizes(64, 64, 64, 256)                       # configs[1]
     assert fwd == bwd == ws_bytes(3 * 128)
