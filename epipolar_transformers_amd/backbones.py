@@ -211,14 +211,72 @@ class PoseResNet(nn.Module):
         return feature, [heatmap], locs, scos, corr_pos, depth, sample_locs, None
 
     def init_weights(self, pretrained=None):
-        """Load a trunk checkpoint (state_dict or path); keys that do not exist here are ignored, as the
-        reference's suffix-matching loader does (utils/model_serialization.py:79-108)."""
+        """Load a trunk checkpoint (state_dict or path) the way the reference does (resnet.py:439-471 +
+        utils/model_serialization.py:10-120): the deconvolution head and the final 1x1 convolution are first
+        re-initialised (normal(0, 0.001) weights, BN 1/0), `cfg.WEIGHTS_PREFIX` ('module.' of a DataParallel
+        checkpoint) is stripped / replaced, every parameter of this model takes the loaded tensor whose key is the
+        LONGEST SUFFIX of its own name, and `final_layer.*` is never loaded.  Returns the list of parameters that were
+        matched; raises if nothing matched at all (a silently random-initialised trunk is never what was meant)."""
         if pretrained is None:
-            return
+            return []
+        import logging
+        import warnings
+
+        log = logging.getLogger(__name__)
         state = torch.load(pretrained, map_location="cpu") if isinstance(pretrained, str) else pretrained
-        state = state.get("model", state) if isinstance(state, dict) else state
+        if isinstance(state, dict) and "model" in state:
+            state = state["model"]
+        for m in self.deconv_layers.modules():                              # resnet.py:448-459
+            if isinstance(m, nn.ConvTranspose2d):
+                nn.init.normal_(m.weight, std=0.001)
+                if m.bias is not None:
+                    nn.init.constant_(m.bias, 0)
+            elif isinstance(m, nn.BatchNorm2d):
+                nn.init.constant_(m.weight, 1)
+                nn.init.constant_(m.bias, 0)
+        nn.init.normal_(self.final_layer.weight, std=0.001)                 # resnet.py:461-467
+        nn.init.constant_(self.final_layer.bias, 0)
+        # strip_prefix_if_present (model_serialization.py:62-80)
+        prefix = getattr(self.cfg, "WEIGHTS_PREFIX", "module.")
+        replace = getattr(self.cfg, "WEIGHTS_PREFIX_REPLACE", "")
+        allow = getattr(self.cfg, "WEIGHTS_ALLOW_DIFF_PREFIX", False)
+        keys = sorted(state.keys())
+        if all(k.startswith(prefix) for k in keys) or allow:
+            if not all(k.startswith(prefix) for k in keys):
+                warnings.warn("[Warning] Not all keys contain the prefix " + prefix)
+            stripped = {}
+            for k, v in state.items():
+                if k != "" and not k.startswith(prefix):
+                    continue
+                stripped[(replace + k) if (prefix == "" and replace != "") else k.replace(prefix, replace)] = v
+            state = stripped
+        elif prefix:
+            warnings.warn("[Warning] Not all keys contain the prefix " + prefix)
+        # align_and_update_state_dicts (model_serialization.py:10-60): longest loaded key that is a suffix
         own = self.state_dict()
-        self.load_state_dict({k: v for k, v in state.items() if k in own and own[k].shape == v.shape}, strict=False)
+        ignored = ("final_layer.bias", "final_layer.weight")
+        loaded_keys = sorted(state.keys())
+        matched, update = [], {}
+        for k in sorted(own.keys()):
+            if k in ignored:
+                continue
+            best = max((j for j in loaded_keys if k.endswith(j)), key=len, default=None)
+            if best is None:
+                continue
+            if tuple(state[best].shape) != tuple(own[k].shape):
+                raise RuntimeError("checkpoint tensor %s %s does not fit parameter %s %s" %
+                                   (best, tuple(state[best].shape), k, tuple(own[k].shape)))
+            update[k] = state[best]
+            matched.append(k)
+        trunk = [k for k in own if not k.startswith(("final_layer.", "epipolar_sampler")) and "num_batches_tracked" not in k]
+        if not matched:
+            raise RuntimeError("checkpoint has no key matching this model (WEIGHTS_PREFIX=%r): nothing was loaded" % prefix)
+        missing = [k for k in trunk if k not in update]
+        if missing:
+            log.warning("init_weights: %d of %d trunk tensors not found in the checkpoint (first: %s)",
+                        len(missing), len(trunk), missing[0])
+        self.load_state_dict(update, strict=False)
+        return matched
 
 
 def get_pose_net(cfg=None, **kwargs):

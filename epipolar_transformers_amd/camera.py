@@ -110,16 +110,24 @@ def pair_algebra(P_ref: torch.Tensor, P_src: torch.Tensor) -> torch.Tensor:
 
 class PairAlgebraCache:
     """Small value-keyed cache (camera rigs repeat across frames and steps).
-    Keyed on the bytes of the matrices, never on tensor identity (SURVEY.md 8b
-    "Ownership")."""
+    Keyed on the BYTES of the matrices, never on tensor identity: a data loader frees and re-allocates its batches,
+    and a recycled address with different matrices must not hit (SURVEY.md 8b "Ownership").
+
+    A caller that hands GPU-resident matrices -- the reference's Modelbuilder does, after
+    `batchdata.to(device)` (model.py:183-195) -- pays one small blocking device-to-host copy per call to form the
+    key.  Pass `host=(P_ref_cpu, P_src_cpu)`, the copies the data loader produced anyway, to keep the launch path
+    asynchronous (main.py's launcher does).  Parity note: the algebra is float32 LAPACK on the HOST (pinverse /
+    inverse), the reference's CPU path; a reference running pinverse on a GPU can differ in the last bits, and the
+    layer is discontinuous in them."""
 
     def __init__(self, max_entries: int = 8):
         self.max_entries = max_entries
         self._store = {}
 
-    def get(self, P_ref: torch.Tensor, P_src: torch.Tensor, device) -> torch.Tensor:
-        a = P_ref.detach().to("cpu", torch.float32).contiguous()
-        b = P_src.detach().to("cpu", torch.float32).contiguous()
+    def get(self, P_ref: torch.Tensor, P_src: torch.Tensor, device, host=None) -> torch.Tensor:
+        src_a, src_b = host if host is not None else (P_ref, P_src)
+        a = src_a.detach().to("cpu", torch.float32).contiguous()
+        b = src_b.detach().to("cpu", torch.float32).contiguous()
         key = (a.numpy().tobytes(), b.numpy().tobytes(), str(device))
         hit = self._store.get(key)
         if hit is None:

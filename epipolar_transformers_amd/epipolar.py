@@ -3,7 +3,7 @@
 same 4-tuple, same parameter names (`z.weight`, `z.bias`, `bn.*`) so released
 checkpoints load.  The Python per-sample loop, the two grid_sample calls and
 the K x C x H x W intermediates are replaced by one fused HIP kernel
-(csrc/epipolar_kernels.hip) behind the C ABI of include/epipolar_amd.h.
+(csrc/et_forward*.hip) behind the C ABI of include/epipolar_amd.h.
 
 Supported here is the mode every shipped epipolar config runs
 (SURVEY.md section 0): ATTENTION avg, SIMILARITY dot, soft-max on or off,
@@ -96,9 +96,18 @@ class Epipolar(nn.Module):
             raise NotImplementedError("not on the fused MI355X path yet: " + ", ".join(unsupported))
 
     # --------------------------------------------------------------- forward
+    host_P = None    # optional (P_ref_cpu, P_src_cpu) of the CURRENT batch, set by a launcher that still has the data
+                     # loader's host copies: spares the device-to-host copy of GPU-resident matrices (camera.py)
+
+    def _cam(self, P1, P2, device):
+        host = self.host_P
+        if host is not None and (tuple(host[0].shape) != tuple(P1.shape) or tuple(host[1].shape) != tuple(P2.shape)):
+            host = None
+        return self._cams.get(P1, P2, device, host=host)
+
     def attend(self, feat1, feat2, P1, P2):
         """The fused kernel only: (out, attn, corr_pos), `out` before the z branch."""
-        cam = self._cams.get(P1, P2, feat1.device)
+        cam = self._cam(P1, P2, feat1.device)
         return ops.EpipolarAttend.apply(feat1, feat2, cam, self.layer_spec())
 
     def _folded_z(self):
@@ -117,8 +126,11 @@ class Epipolar(nn.Module):
         if not bool(amd_knob(cfg, "FUSED_EPILOGUE", True)):
             return False
         has_z = "z" in cfg.EPIPOLAR.PARAMETERIZED
+        # the folded epilogue consumes z / bn inside a HIP kernel and an out= GEMM: no autograd through it, so
+        # it is taken only when NO parameter of the branch (and no input) asks for a gradient
         if torch.is_grad_enabled() and (any(t.requires_grad for t in tensors) or
-                                        (has_z and self.z.weight.requires_grad)):
+                                        (has_z and any(q.requires_grad for q in
+                                                       list(self.z.parameters()) + list(self.bn.parameters())))):
             return False
         return not (has_z and self.bn.training)
 
@@ -136,6 +148,11 @@ class Epipolar(nn.Module):
         feat1, feat2: N x C x H x W ; P1, P2: N x 3 x 4
         returns (finalout, corr_pos[N,H,W,2], depth[N,K,H,W], sample_locs | None)."""
         self._check_mode(depth, ref1, ref2)
+        if self.debug:
+            # the reference's debug mode returns a 9-tuple with the intermediate geometry (epipolar.py:264-265);
+            # the fused kernels never materialise it
+            raise NotImplementedError("Epipolar(debug=True): the 9-tuple of geometry intermediates is not produced by "
+                                      "the fused path; use VIS.EPIPOLAR_LINE for sample_locs")
         out, attn, corr_pos = self.attend(feat1, feat2, P1, P2)
         if self._eval_fast_path((feat1, feat2)) and "z" in self.cfg.EPIPOLAR.PARAMETERIZED:
             # one GEMM (hipBLASLt, fp32 MFMA) with the bias in its epilogue
@@ -145,11 +162,9 @@ class Epipolar(nn.Module):
         else:
             finalout, _ = self._epilogue_torch(out)
         sample_locs = None
-        if self.debug or self.cfg.VIS.EPIPOLAR_LINE:
-            cam = self._cams.get(P1, P2, feat1.device)
-            sample_locs = ops.sample_locs(self.layer_spec(), cam)            # (K,N,H,W,2)
-            if not self.debug:
-                sample_locs = sample_locs.transpose(0, 1)                    # epipolar.py:267
+        if self.cfg.VIS.EPIPOLAR_LINE:
+            cam = self._cam(P1, P2, feat1.device)
+            sample_locs = ops.sample_locs(self.layer_spec(), cam).transpose(0, 1)   # (K,N,H,W,2) -> epipolar.py:267
         return finalout, corr_pos, attn, sample_locs
 
     def forward_fused(self, feat1, feat2, P1, P2):
@@ -161,7 +176,7 @@ class Epipolar(nn.Module):
             out, attn, corr_pos = self.attend(feat1, feat2, P1, P2)
             _, x = self._epilogue_torch(out, feat1)
             return x, corr_pos, attn, None
-        cam = self._cams.get(P1, P2, feat1.device)
+        cam = self._cam(P1, P2, feat1.device)
         ref, src = ops.to_nhwc(feat1), ops.to_nhwc(feat2)
         if "z" in self.cfg.EPIPOLAR.PARAMETERIZED:
             wt, bf = self._folded_z()

@@ -83,26 +83,33 @@ class ViewShardExchange:
             self._own_group = groups[self.slice_id]
         return self._own_group
 
+    def _gather_flat(self, send: torch.Tensor, pg, async_op=False):
+        """ONE all_gather_into_tensor of `send` over the view group: (G, *send.shape), no per-rank list copies."""
+        g = len(self.group_ranks)
+        flat = torch.empty((g * send.shape[0],) + tuple(send.shape[1:]), dtype=send.dtype, device=send.device)
+        work = dist.all_gather_into_tensor(flat, send.contiguous(), group=pg, async_op=async_op)   # concatenation along dim 0
+        return flat.view((g,) + tuple(send.shape)), work
+
     def gather_sources(self, own_maps: torch.Tensor) -> torch.Tensor:
         """own_maps: this rank's (len(my_cams)*frames, H, W, C) maps, camera-major.
         Returns the source maps of its pairs, same order, after ONE all-gather of
-        the per-rank maps over the view group."""
+        the per-rank maps over the view group (a VIEW of the receive buffer when the rank owns one camera)."""
         pg = self._pg()
-        parts = [torch.empty_like(own_maps) for _ in self.group_ranks]
-        dist.all_gather(parts, own_maps.contiguous(), group=pg)
+        recv, _ = self._gather_flat(own_maps, pg)
         f = own_maps.shape[0] // len(self.my_cams)
         chunks = []
         for cam in self.my_cams:
             owner, idx = self.source_location(cam)
-            chunks.append(parts[self.group_ranks.index(owner)][idx * f:(idx + 1) * f])
+            chunks.append(recv[self.group_ranks.index(owner), idx * f:(idx + 1) * f])
         return chunks[0] if len(chunks) == 1 else torch.cat(chunks)
 
     def gather_sources_chunked(self, own_maps: torch.Tensor, num_chunks: int):
         """Overlappable form of gather_sources: the frames of every camera are split in `num_chunks` ranges and
         each range is all-gathered as its own asynchronous collective (RCCL runs them on its stream).  Yields
-        `(pair_index_tensor, source_maps)` per chunk after waiting for THAT chunk only, so the caller's fused
-        kernel on chunk i overlaps the transfer of chunks i+1.. (xGMI: a 128 MiB shard takes ~0.9 ms per
-        link -- the same order as the kernel)."""
+        `(ranges, source_maps)` per chunk after waiting for THAT chunk only -- `ranges` = one (start, stop) slice of
+        the rank's pair list per owned camera (contiguous frame ranges: the caller slices its reference maps and
+        camera algebra with them, no index gather) -- so the caller's fused kernel on chunk i overlaps the transfer
+        of chunks i+1.. (xGMI: a 128 MiB shard takes ~0.9 ms per link -- the same order as the kernel)."""
         pg = self._pg()
         ncam = len(self.my_cams)
         f = own_maps.shape[0] // ncam
@@ -111,31 +118,126 @@ class ViewShardExchange:
         per_cam = own_maps.view(ncam, f, *own_maps.shape[1:])
         inflight = []
         for lo, hi in zip(bounds[:-1], bounds[1:]):
-            send = per_cam[:, lo:hi].contiguous()                       # (ncam, hi-lo, ...)
-            parts = [torch.empty_like(send) for _ in self.group_ranks]
-            work = dist.all_gather(parts, send, group=pg, async_op=True)
-            inflight.append((lo, hi, parts, work))
-        for lo, hi, parts, work in inflight:
+            send = per_cam[:, lo:hi]                                   # (ncam, hi-lo, ...): contiguous when ncam == 1
+            recv, work = self._gather_flat(send, pg, async_op=True)
+            inflight.append((lo, hi, recv, work))
+        for lo, hi, recv, work in inflight:
             work.wait()
-            chunks, index = [], []
+            chunks, ranges = [], []
             for ci, cam in enumerate(self.my_cams):
                 owner, idx = self.source_location(cam)
-                chunks.append(parts[self.group_ranks.index(owner)][idx])
-                index.append(torch.arange(ci * f + lo, ci * f + hi))
-            yield torch.cat(index), (chunks[0] if len(chunks) == 1 else torch.cat(chunks))
+                chunks.append(recv[self.group_ranks.index(owner), idx])
+                ranges.append((ci * f + lo, ci * f + hi))
+            yield ranges, (chunks[0] if len(chunks) == 1 else torch.cat(chunks))
 
     def scatter_source_grads(self, grad_src: torch.Tensor) -> torch.Tensor:
-        """Backward of gather_sources: route d(source maps) back to the ranks that
-        own those maps and sum (reduce-scatter semantics, done as all-gather + local
-        sum so it also runs on gloo)."""
+        """Backward of gather_sources: route d(source maps) back to the ranks that own those maps.  Every map is
+        the source of exactly ONE reference camera (ring pairing), so this is a permutation, not a reduction: one
+        all_to_all_single in which a rank sends each camera's gradient block to its owner only -- 1x the data, where
+        an all-gather (or a reduce-scatter over zero-padded slots) would move G x."""
         pg = self._pg()
-        parts = [torch.empty_like(grad_src) for _ in self.group_ranks]
-        dist.all_gather(parts, grad_src.contiguous(), group=pg)
-        f = grad_src.shape[0] // len(self.my_cams)
-        out = torch.zeros_like(grad_src)
-        for gi, r in enumerate(self.group_ranks):
-            for ci, cam in enumerate(self.cams_of[r]):
-                owner, idx = self.source_location(cam)
-                if owner == self.rank:
-                    out[idx * f:(idx + 1) * f] += parts[gi][ci * f:(ci + 1) * f]
-        return out
+        ncam = len(self.my_cams)
+        f = grad_src.shape[0] // ncam
+        per = grad_src.reshape(ncam, f, -1)
+        width = per.shape[2]
+        # send side: my blocks grouped by destination rank (group order), camera order inside
+        send_blocks, send_split = [], []
+        for r in self.group_ranks:
+            mine = [ci for ci, cam in enumerate(self.my_cams) if self.source_location(cam)[0] == r]
+            send_blocks += [per[ci] for ci in mine]
+            send_split.append(len(mine) * f)
+        # receive side: from rank q, the blocks of q's cameras whose source I own, in q's camera order
+        recv_split, recv_slots = [], []
+        for q in self.group_ranks:
+            slots = [self.source_location(cam)[1] for cam in self.cams_of[q] if self.source_location(cam)[0] == self.rank]
+            recv_split.append(len(slots) * f)
+            recv_slots += slots
+        send = torch.cat(send_blocks) if send_blocks else per.new_zeros((0, width))
+        recv = torch.empty((sum(recv_split), width), dtype=grad_src.dtype, device=grad_src.device)
+        dist.all_to_all_single(recv, send.contiguous(), output_split_sizes=recv_split, input_split_sizes=send_split, group=pg)
+        out = torch.zeros_like(per)
+        for k, idx in enumerate(recv_slots):
+            out[idx] += recv[k * f:(k + 1) * f]
+        return out.view_as(grad_src)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Cross-rank coupling of the layer in TRAINING: the batch statistics of the z-epilogue's BN
+# ---------------------------------------------------------------------------------------------------------------
+class _SyncBNFunction(torch.autograd.Function):
+    """Batch norm over (N,H,W) of ALL ranks: per-channel sum / sum of squares / count go through one all-reduce in the
+    forward, sum(dy) / sum(dy * xhat) through one in the backward (what the reference's SynchronizedBatchNorm2d does
+    between DataParallel replicas, modeling/sync_batchnorm/batchnorm.py:114-122, here between processes)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, eps, group):
+        c = x.shape[1]
+        xf = x.float()
+        stats = torch.cat([xf.sum((0, 2, 3)), (xf * xf).sum((0, 2, 3)), xf.new_tensor([x.numel() / c])])
+        dist.all_reduce(stats, group=group)
+        count = stats[-1]
+        mean = stats[:c] / count
+        var = (stats[c:2 * c] / count - mean * mean).clamp_min_(0)
+        invstd = torch.rsqrt(var + eps)
+        xhat = (xf - mean.view(1, c, 1, 1)) * invstd.view(1, c, 1, 1)
+        ctx.save_for_backward(xhat, invstd, weight)
+        ctx.group, ctx.count = group, count
+        y = xhat * weight.view(1, c, 1, 1) + bias.view(1, c, 1, 1)
+        ctx.mark_non_differentiable(mean, var)
+        return y.to(x.dtype), mean, var, count
+
+    @staticmethod
+    def backward(ctx, dy, _dm, _dv, _dc):
+        xhat, invstd, weight = ctx.saved_tensors
+        c = dy.shape[1]
+        dyf = dy.float()
+        local = torch.cat([dyf.sum((0, 2, 3)), (dyf * xhat).sum((0, 2, 3))])
+        dweight, dbias = local[c:].clone(), local[:c].clone()             # parameter grads stay local (DDP sums them)
+        dist.all_reduce(local, group=ctx.group)
+        mean_dy = (local[:c] / ctx.count).view(1, c, 1, 1)
+        mean_dy_xhat = (local[c:] / ctx.count).view(1, c, 1, 1)
+        dx = (dyf - mean_dy - xhat * mean_dy_xhat) * (invstd * weight).view(1, c, 1, 1)
+        return dx.to(dy.dtype), dweight, dbias, None, None
+
+
+class SyncBatchNorm2d(torch.nn.BatchNorm2d):
+    """Drop-in for the layer's `bn` (same parameters / buffers / state_dict keys) whose TRAINING statistics span the
+    process group -- cfg.BACKBONE.SYNC_BN (configs/epipolar/keypoint_h36m_resnet152_384_pretrained_8gpu.yaml:21;
+    the reference converts with convert_model at modeling/model.py:56-58).  Works on any torch.distributed backend
+    (RCCL on the GPUs; gloo in the CPU tests), falls back to plain batch norm outside a process group or in eval."""
+
+    process_group = None
+
+    def forward(self, x):
+        if not (self.training and dist.is_available() and dist.is_initialized() and
+                dist.get_world_size(self.process_group) > 1):
+            return super().forward(x)
+        y, mean, var, count = _SyncBNFunction.apply(x, self.weight, self.bias, self.eps, self.process_group)
+        if self.track_running_stats:
+            with torch.no_grad():
+                self.num_batches_tracked += 1
+                m = self.momentum if self.momentum is not None else 1.0 / float(self.num_batches_tracked)
+                unbiased = var * (count / (count - 1).clamp_min(1))
+                self.running_mean.mul_(1 - m).add_(mean.to(self.running_mean.dtype), alpha=m)
+                self.running_var.mul_(1 - m).add_(unbiased.to(self.running_var.dtype), alpha=m)
+        return y
+
+
+def convert_sync_batchnorm(module: torch.nn.Module, process_group=None) -> torch.nn.Module:
+    """Replace every BatchNorm2d (incl. the layer's zeroinitBN) below `module` by SyncBatchNorm2d, in place of the
+    reference's `convert_model` (sync_batchnorm/batchnorm.py:379-386).  Parameters and buffers are shared, so
+    checkpoints keep loading."""
+    for name, child in list(module.named_children()):
+        if isinstance(child, torch.nn.BatchNorm2d) and not isinstance(child, SyncBatchNorm2d):
+            new = SyncBatchNorm2d(child.num_features, child.eps, child.momentum, child.affine, child.track_running_stats)
+            new.process_group = process_group
+            if child.affine:
+                new.weight, new.bias = child.weight, child.bias
+            if child.track_running_stats:
+                new.running_mean, new.running_var = child.running_mean, child.running_var
+                new.num_batches_tracked = child.num_batches_tracked
+            new.train(child.training)
+            setattr(module, name, new)
+        else:
+            convert_sync_batchnorm(child, process_group)
+    return module

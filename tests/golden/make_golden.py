@@ -43,6 +43,10 @@ CASES = [
     dict(name="h36m_64x64_c8_k64", H=64, C=8, K=64, frames=1, image=256, jitter=(0.05, 8.0), relu=True, correct=True, softmax=True, pairs=1, rows=(0, 13, 31, 50, 63)),
     dict(name="k128_32x32_c8", H=32, C=8, K=128, frames=1, image=128, jitter=(0.02, 2.0), relu=True, correct=True, softmax=True, pairs=1, rows=(0, 9, 17, 31)),
     dict(name="views8_16x16_c8_k16", H=16, C=8, K=16, frames=1, image=64, jitter=None, relu=True, correct=True, softmax=True, views=8),
+    # the 256-channel head: these go through the MFMA tile kernels (forward and backward), so those are pinned to
+    # outputs of the real reference directly and not only through the C oracle
+    dict(name="head_16x16_c256_k16", H=16, C=256, K=16, frames=1, image=64, jitter=(0.05, 3.0), relu=True, correct=True, softmax=True, pairs=2),
+    dict(name="head_24x24_c256_k33", H=24, C=256, K=33, frames=1, image=96, jitter=(0.05, 5.0), relu=True, correct=True, softmax=True, pairs=1),
 ]
 
 
@@ -116,7 +120,10 @@ def main():
     warnings.simplefilter("ignore")
     torch.set_num_threads(4)
     outdir = os.path.dirname(os.path.abspath(__file__))
+    only = set(sys.argv[1:])          # optional: names of the cases to (re)generate; default all
     for c in CASES:
+        if only and c["name"] not in only:
+            continue
         data = run_case(c)
         path = os.path.join(outdir, c["name"] + ".npz")
         np.savez_compressed(path, **data)

@@ -77,3 +77,24 @@ def test_backward_matches_reference_autograd(oracle_mod, case):
     for got, want in ((g1, d["grad_feat1"]), (g2, d["grad_feat2"])):
         scale = np.abs(want).max()
         assert np.abs(got - want).max() <= 1e-4 * scale, (np.abs(got - want).max(), scale)
+
+
+@pytest.mark.parametrize("case", golden_cases())
+def test_torch_op_sequence_vs_reference(case):
+    """oracle/torch_ref_path.py (the reference's executed op sequence, used as bench.py's "reference-op-sequence"
+    CPU baseline) reproduces the real reference's outputs on the fixtures."""
+    import torch
+
+    from oracle import torch_ref_path as trp
+
+    d = load_golden(case)
+    m = d["dims"]
+    from oracle import oracle as orc
+    orc.build()
+    locs = orc.sample_locs(_spec(orc, d), None, None, cam=d["cam"])
+    out, attn, corr = trp.forward(torch.from_numpy(d["feat1"]), torch.from_numpy(d["feat2"]), torch.from_numpy(locs),
+                                  softmax_scale=float(d["softmax_scale"]), softmax_enabled=m["softmax"],
+                                  correct_normalize=m["correct"])
+    assert np.abs(out.numpy() - d["out"]).max() <= 5e-6 * max(1.0, float(np.abs(d["out"]).max()))
+    assert np.abs(attn.numpy()[:, :, d["rows"]] - d["attn"]).max() <= 1e-6 * max(1.0, float(np.abs(d["attn"]).max()))
+    assert ((corr.numpy() != d["corr_pos"]).any(-1)).mean() <= 1e-3

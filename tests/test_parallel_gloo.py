@@ -37,9 +37,12 @@ def _worker(rank, world, port, V, frames, errs):
         # chunked / overlappable form: same maps, delivered in frame ranges
         got = torch.empty_like(want)
         seen = 0
-        for idx, maps in ex.gather_sources_chunked(own, 2):
-            got[idx] = maps
-            seen += idx.numel()
+        for ranges, maps in ex.gather_sources_chunked(own, 2):
+            off = 0
+            for a, b in ranges:
+                got[a:b] = maps[off:off + (b - a)]
+                off += b - a
+            seen += off
         assert seen == want.shape[0] and torch.equal(got, want), "rank %d chunked gather mismatch" % rank
         # projection matrices follow the same pairing: the source matrix of (frame, v) is the
         # reference matrix of camera (v+1) % V of the same frame
@@ -96,3 +99,80 @@ def test_frames_partition_covers_everything():
             assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
             sizes = [b - a for a, b in spans]
             assert max(sizes) - min(sizes) <= 1
+
+
+# ---------------------------------------------------------------------------------------
+# SyncBN of the layer's z-epilogue (training-time coupling across ranks, BACKBONE.SYNC_BN)
+# ---------------------------------------------------------------------------------------
+def _syncbn_worker(rank, world, port, errs):
+    try:
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        from epipolar_transformers_amd import default_cfg
+        from epipolar_transformers_amd.epipolar import Epipolar
+        from epipolar_transformers_amd.parallel import SyncBatchNorm2d, convert_sync_batchnorm
+
+        C, H = 8, 6
+        cfg = default_cfg()
+        cfg.merge_from_list(["KEYPOINT.HEATMAP_SIZE", (H, H), "KEYPOINT.NFEATS", C, "EPIPOLAR.PARAMETERIZED", ("z",),
+                             "EPIPOLAR.ZRESIDUAL", True])
+        torch.manual_seed(0)                               # same weights and the same GLOBAL batch on every rank
+        single = Epipolar(cfg=cfg)
+        with torch.no_grad():
+            single.bn.weight.normal_(1, 0.1)
+            single.bn.bias.normal_(0, 0.1)
+        out_all = torch.randn(2 * world, C, H, H)
+        gout_all = torch.randn(2 * world, C, H, H)
+        keys_before = sorted(single.state_dict())
+        import copy
+        multi = convert_sync_batchnorm(copy.deepcopy(single))
+        assert isinstance(multi.bn, SyncBatchNorm2d) and sorted(multi.state_dict()) == keys_before
+        single.train()
+        multi.train()
+        # reference: ONE process, the whole batch, plain batch norm (what the reference gets from its
+        # SynchronizedBatchNorm2d across DataParallel replicas, sync_batchnorm/batchnorm.py:114-122)
+        a = out_all.clone().requires_grad_(True)
+        fin_all, _ = single._epilogue_torch(a)
+        (fin_all * gout_all).sum().backward()
+        # this rank: its shard only, statistics synchronised
+        sl = slice(2 * rank, 2 * rank + 2)
+        b = out_all[sl].clone().requires_grad_(True)
+        fin, _ = multi._epilogue_torch(b)
+        (fin * gout_all[sl]).sum().backward()
+        assert torch.allclose(fin, fin_all[sl], atol=1e-5), "rank %d: synced BN output differs" % rank
+        assert torch.allclose(b.grad, a.grad[sl], atol=1e-5), "rank %d: synced BN input gradient differs" % rank
+        assert torch.allclose(multi.bn.running_mean, single.bn.running_mean, atol=1e-6)
+        assert torch.allclose(multi.bn.running_var, single.bn.running_var, atol=1e-5)
+        # parameter gradients are per-rank partial sums (DDP / an all-reduce adds them up)
+        gw = multi.bn.weight.grad.clone()
+        dist.all_reduce(gw)
+        assert torch.allclose(gw, single.bn.weight.grad, atol=1e-4)
+        gz = multi.z.weight.grad.clone()
+        dist.all_reduce(gz)
+        assert torch.allclose(gz, single.z.weight.grad, atol=1e-4)
+        # eval mode: no coupling, identical to the plain layer
+        multi.eval(); single.eval()
+        with torch.no_grad():
+            assert torch.allclose(multi._epilogue_torch(out_all[sl])[0], single._epilogue_torch(out_all[sl])[0], atol=1e-6)
+        dist.barrier()
+        dist.destroy_process_group()
+    except Exception as exc:  # pragma: no cover
+        errs.put("rank %d: %r" % (rank, exc))
+        raise
+
+
+def test_sync_batchnorm_epilogue_matches_single_process_gloo():
+    ctx = mp.get_context("spawn")
+    errs = ctx.SimpleQueue()
+    port = _free_port()
+    world = 2
+    procs = [ctx.Process(target=_syncbn_worker, args=(r, world, port, errs)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(180)
+    msgs = []
+    while not errs.empty():
+        msgs.append(errs.get())
+    assert not msgs, msgs
+    assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
