@@ -286,7 +286,8 @@ def end_to_end(args, dev, P_ref, P_src, frames, V):
     """epipolarposeR-50 on `frames` x V synthetic 256x256 images (random init, fp32, eval): the trunk runs ONCE per
     view (the reference runs it twice per pair, model.py:241-247 -- SURVEY.md N1), its channels_last deconv
     features feed the fused layer directly, then the 1x1 head and the batched peak finder."""
-    from epipolar_transformers_amd import backbones, default_cfg
+    from epipolar_transformers_amd import default_cfg
+    from epipolar_transformers_amd.model import MultiViewPoseModel, ring_sources
 
     cfg = default_cfg()
     cfg.merge_from_list(["BACKBONE.BODY", "epipolarposeR-50", "BACKBONE.PRETRAINED", False,
@@ -295,17 +296,14 @@ def end_to_end(args, dev, P_ref, P_src, frames, V):
                          "EPIPOLAR.MERGE", "late", "EPIPOLAR.ATTENTION", "avg", "EPIPOLAR.PARAMETERIZED", ("z",),
                          "EPIPOLAR.ZRESIDUAL", True, "EPIPOLAR.USE_CORRECT_NORMALIZE", True,
                          "EPIPOLAR.SAMPLESIZE", args.samples])
-    net = backbones.build_backbone(cfg).to(dev).eval().to(memory_format=torch.channels_last)
+    net = MultiViewPoseModel(cfg).to(dev).eval().to(memory_format=torch.channels_last)
     n = frames * V
     img = torch.randn(n, 3, args.hw * 4, args.hw * 4, device=dev).contiguous(memory_format=torch.channels_last)
-    idx = torch.arange(n, device=dev).view(frames, V).roll(-1, 1).reshape(-1)       # ring neighbour of each view
+    idx = ring_sources(frames, V, dev)                                                # ring neighbour of each view
 
     def step():
         with torch.no_grad():
-            feats = net(img)[0]                                   # trunk + deconv head, every view once
-            x, corr, depth, _ = net.epipolar_sampler.forward_fused(feats, feats[idx], P_ref, P_src)
-            heat = net.final_layer(x)
-            return backbones.soft_argmax_peaks(heat, 8.0, 4)
+            return net.forward_views(img, P_ref, idx)                                 # trunk once per view, fused layer, head, peaks
 
     for _ in range(3):
         step()
@@ -330,7 +328,7 @@ def mpjpe_delta(dev):
     if not os.path.exists(path):
         return None
     from epipolar_transformers_amd import default_cfg
-    from epipolar_transformers_amd.backbones import soft_argmax_peaks
+    from epipolar_transformers_amd.backbones import find_peaks as soft_argmax_peaks
     from epipolar_transformers_amd.epipolar import Epipolar
     from epipolar_transformers_amd.triangulate import mpjpe, triangulate_dlt
 

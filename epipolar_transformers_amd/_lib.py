@@ -69,6 +69,8 @@ _SIGNATURES = {
     "et_epipolar_backward_workspace_bytes": (ctypes.c_size_t, [_D]),
     "et_epipolar_backward": (ctypes.c_int, [_D, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, ctypes.c_size_t, _P]),
     "et_residual_epilogue": (ctypes.c_int, [ctypes.c_int64, ctypes.c_int32, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "et_heatmap_peaks": (ctypes.c_int, [ctypes.c_int64, ctypes.c_int32, ctypes.c_int32, _P, ctypes.c_float, ctypes.c_float,
+                                        ctypes.c_float, ctypes.c_int32, _P, _P, _P]),
     "et_nchw_to_nhwc": (ctypes.c_int, [ctypes.c_int32] * 4 + [_P, _P, _P]),
     "et_nhwc_to_nchw": (ctypes.c_int, [ctypes.c_int32] * 4 + [_P, _P, _P]),
     "et_debug_host_sample_setup": (ctypes.c_int, [_D, _P, _P, _P, _P, ctypes.c_int32, ctypes.c_int32, _P, _P, _P]),

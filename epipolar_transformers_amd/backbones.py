@@ -129,6 +129,16 @@ def soft_argmax_peaks(heatmaps: torch.Tensor, radius: float, downsample: int, th
     return torch.stack([x, y], 1).view(n, j, 2), score.view(n, j)
 
 
+def find_peaks(heatmaps: torch.Tensor, radius: float, downsample: float, legacy_floor_division: bool = False):
+    """Peak finder of the head: the fused HIP kernel (ops.heatmap_peaks, one launch) for float32 heat maps on the GPU,
+    the batched torch restatement (soft_argmax_peaks) otherwise (CPU plumbing runs of the single-view net)."""
+    if heatmaps.is_cuda and heatmaps.dtype == torch.float32:
+        from . import ops
+
+        return ops.heatmap_peaks(heatmaps, radius, downsample, legacy_floor_division=legacy_floor_division)
+    return soft_argmax_peaks(heatmaps, radius, downsample, legacy_floor_division=legacy_floor_division)
+
+
 class PoseResNet(nn.Module):
     def __init__(self, block, layers, cfg, **kwargs):
         super().__init__()
@@ -179,7 +189,15 @@ class PoseResNet(nn.Module):
             ret, corr_pos, depth, sample_locs = sampler(feat, other_features, KRT, other_KRT,
                                                         camera=camera, other_camera=other_camera)
             return ret + feat, corr_pos, depth, sample_locs
-        return sampler.forward_fused(feat, other_features, KRT, other_KRT)
+        return sampler.forward_fused(feat, other_features, KRT, other_KRT, camera=camera, other_camera=other_camera)
+
+    def trunk(self, x):
+        """Image -> the pre-fusion feature map of resnet.py:406 (ResNet stages + the three deconvolutions), without
+        any fusion: what `forward(x, other_inputs=None)` returns as element 0 (model.py:244 calls it for that)."""
+        if x.is_cuda:
+            x = x.contiguous(memory_format=torch.channels_last)             # NHWC all the way to the fused kernel
+        x = self.layer1(self.maxpool(self.relu(self.bn1(self.conv1(x)))))
+        return self.deconv_layers(self.layer4(self.layer3(self.layer2(x))))
 
     def forward(self, x, other_inputs=(None, None, None, None, None, None, None)):
         other_features, other_KRT, other_heatmaps, KRT, camera, other_camera, other_img = other_inputs
@@ -205,7 +223,7 @@ class PoseResNet(nn.Module):
         else:
             x = feature
         heatmap = self.final_layer(x)
-        locs, scos = soft_argmax_peaks(heatmap, self.cfg.KEYPOINT.SIGMA, self.cfg.BACKBONE.DOWNSAMPLE)
+        locs, scos = find_peaks(heatmap, self.cfg.KEYPOINT.SIGMA, self.cfg.BACKBONE.DOWNSAMPLE)
         if other_features is None:
             corr_pos, depth = None, None
         return feature, [heatmap], locs, scos, corr_pos, depth, sample_locs, None

@@ -86,4 +86,15 @@ int et_debug_host_sample_setup(const EtLayerDesc *desc, const float *xs, const f
     return 0;
 }
 
+int et_heatmap_peaks(int64_t num_maps, int32_t H, int32_t W, const float *heatmaps, float radius, float downsample,
+                     float threshold, int32_t legacy_floor_division, float *locs, float *scores, void *stream)
+{
+    if (num_maps <= 0 || num_maps > 0x7fffffffLL || H < 2 || W < 2) return fail("et_heatmap_peaks: bad sizes");
+    if (!(radius > 0.f) || (int)(radius + 0.5f) < 1) return fail("et_heatmap_peaks: radius %g", radius);
+    if (!heatmaps || !locs || !scores) return fail("et_heatmap_peaks: NULL pointer");
+    hipLaunchKernelGGL(heatmap_peaks_kernel, dim3((unsigned)num_maps), dim3(256), 0, (hipStream_t)stream, heatmaps, H, W,
+                       radius, downsample, threshold, legacy_floor_division, locs, scores);
+    return check_launch("et_heatmap_peaks");
+}
+
 }  // extern "C"

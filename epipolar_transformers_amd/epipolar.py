@@ -5,12 +5,13 @@ checkpoints load.  The Python per-sample loop, the two grid_sample calls and
 the K x C x H x W intermediates are replaced by one fused HIP kernel
 (csrc/et_forward*.hip) behind the C ABI of include/epipolar_amd.h.
 
-Supported here is the mode every shipped epipolar config runs
-(SURVEY.md section 0): ATTENTION avg, SIMILARITY dot, soft-max on or off,
-optional 'z' (+BN, +ZRESIDUAL), either normalize convention.  The ablation
-branches (theta/phi/g bottleneck, POOLING, PRIOR, ATTENTION max, cosine,
-FIND_CORR rgb, reprojection loss, given depth) raise NotImplementedError --
-they are rows "next N4" of SURVEY.md section 8f, not silently approximated.
+The mode every headline config runs -- ATTENTION avg, SIMILARITY dot, soft-max on or off,
+optional 'z' (+BN, +ZRESIDUAL), either normalize convention -- takes the fused HIP kernels.  The operator's
+other branches (theta/phi/g bottleneck, POOLING, ATTENTION max, cosine similarity,
+PRIOR / PRIORMUL, FIND_CORR rgb -- e.g. configs/epipolar/keypoint_h36m_param.yaml) run on the GPU as a restatement
+of the reference's own op sequence (`_attend_general`): the sample locations still come from the HIP geometry
+kernel (bit-equal to grid2sample_locs), the resampling / pooling / similarity are batched torch ops with autograd.
+The reprojection loss and an externally supplied depth raise NotImplementedError.
 """
 from __future__ import annotations
 
@@ -45,16 +46,22 @@ class Epipolar(nn.Module):
         self.sample_size = cfg.EPIPOLAR.SAMPLESIZE
         self.epsilon = 0.001
         nfeats = cfg.KEYPOINT.NFEATS
-        if cfg.EPIPOLAR.BOTTLENECK != 1:
-            raise NotImplementedError("EPIPOLAR.BOTTLENECK != 1 (theta/phi/g branch) is not on the fused path yet")
-        for name in ("theta", "phi", "g"):
-            if name in cfg.EPIPOLAR.PARAMETERIZED:
-                raise NotImplementedError("EPIPOLAR.PARAMETERIZED %r is not on the fused path yet" % name)
-        if cfg.EPIPOLAR.PRIOR:
-            raise NotImplementedError("EPIPOLAR.PRIOR is not on the fused path yet")
+        bott = cfg.EPIPOLAR.BOTTLENECK
+        if bott != 1:                                                        # epipolar.py:56-61
+            assert all(k in cfg.EPIPOLAR.PARAMETERIZED for k in ("z", "theta", "phi", "g"))
+            assert not cfg.EPIPOLAR.ZRESIDUAL
         if "z" in cfg.EPIPOLAR.PARAMETERIZED:
-            self.z = nn.Conv2d(nfeats, nfeats, kernel_size=1, stride=1, padding=0, bias=True)   # epipolar.py:64
-            self.bn = zeroinitBN(nfeats)                                                        # epipolar.py:65
+            self.z = nn.Conv2d(nfeats // bott, nfeats, kernel_size=1, stride=1, padding=0, bias=True)   # epipolar.py:64
+            self.bn = zeroinitBN(nfeats)                                                                # epipolar.py:65
+        for name in ("theta", "phi", "g"):                                   # epipolar.py:66-71
+            if name in cfg.EPIPOLAR.PARAMETERIZED:
+                setattr(self, name, nn.Conv2d(nfeats, nfeats // bott, kernel_size=1, stride=1, padding=0, bias=True))
+        self.prior = {}
+        if cfg.EPIPOLAR.PRIOR:                                               # epipolar.py:73-80: a plain dict of
+            for i in cfg.DATASETS.CAMERAS:                                   # Parameters, NOT registered (no state_dict keys)
+                for j in cfg.DATASETS.CAMERAS:
+                    if j != i:
+                        self.prior[(i, j)] = nn.Parameter(torch.empty(self.sample_size, self.feat_h, self.feat_w).uniform_(0, 0.1))
         self._spec = None
         self._cams = PairAlgebraCache()
 
@@ -80,20 +87,93 @@ class Epipolar(nn.Module):
         assert e.ATTENTION in {"avg", "max"}                 # epipolar.py:107
         assert e.SIMILARITY in {"cos", "dot", "prior"}        # epipolar.py:108
         unsupported = []
-        if e.ATTENTION != "avg":
-            unsupported.append("ATTENTION=%s" % e.ATTENTION)
-        if e.SIMILARITY != "dot":
-            unsupported.append("SIMILARITY=%s" % e.SIMILARITY)
-        if e.FIND_CORR != "feature" or ref1 is not None or ref2 is not None:
-            unsupported.append("FIND_CORR=rgb")
-        if e.POOLING:
-            unsupported.append("POOLING")
         if e.REPROJECT_LOSS_WEIGHT != 0:
             unsupported.append("REPROJECT_LOSS_WEIGHT")
         if depth is not None:
             unsupported.append("externally supplied depth")
         if unsupported:
-            raise NotImplementedError("not on the fused MI355X path yet: " + ", ".join(unsupported))
+            raise NotImplementedError("not on the MI355X path: " + ", ".join(unsupported))
+
+    def _fused_mode(self, ref1=None, ref2=None) -> bool:
+        """True when the call is the headline mode the fused HIP kernels implement."""
+        e = self.cfg.EPIPOLAR
+        return (e.ATTENTION == "avg" and e.SIMILARITY == "dot" and e.FIND_CORR == "feature" and ref1 is None and
+                ref2 is None and not e.POOLING and not e.PRIOR and e.BOTTLENECK == 1 and
+                not any(k in e.PARAMETERIZED for k in ("theta", "phi", "g")))
+
+    def _attend_general(self, feat1, feat2, P1, P2, camera=None, other_camera=None, ref1=None, ref2=None):
+        """The operator's non-headline branches, restated op for op from epipolar.py:131-247 and
+        epipolar_similarity (:272-321) as batched GPU torch ops (autograd included).  Returns (out, attn, corr_pos)
+        like `attend`; `out` is what the reference stacks at :247 (before z)."""
+        e = self.cfg.EPIPOLAR
+        K, H, W = self.sample_size, self.feat_h, self.feat_w
+        if e.FIND_CORR == "rgb":                                              # epipolar.py:131-136
+            assert ref1 is not None and ref2 is not None
+            assert "other1" not in e.OTHER_GRAD and "phi" not in e.PARAMETERIZED
+            other1, q = ref2.detach(), ref1
+        else:
+            other1 = feat2 if "other1" in e.OTHER_GRAD else feat2.detach()    # :138-141
+            if "phi" in e.PARAMETERIZED:
+                other1 = self.phi(other1)                                     # :142-143
+            q = self.theta(feat1) if "theta" in e.PARAMETERIZED else feat1    # :144-145
+        other2 = feat2 if "other2" in e.OTHER_GRAD else feat2.detach()        # :147-150
+        if "g" in e.PARAMETERIZED:
+            other2 = self.g(other2)                                           # :152-153
+        N = feat2.shape[0]
+        with torch.no_grad():
+            cam = self._cam(P1, P2, feat2.device)
+            locs = ops.sample_locs(self.layer_spec(), cam)                    # (K,N,H,W,2): the HIP geometry kernel
+        align = bool(amd_knob(self.cfg, "ALIGN_CORNERS", False))
+
+        def sample(src):                                                      # :199 / :210, + POOLING :200-202
+            c = src.shape[1]
+            grid = locs.permute(1, 0, 2, 3, 4).reshape(N, K * H, W, 2)        # one grid_sample per map for all K samples
+            s_ = F.grid_sample(src, grid, mode="bilinear", padding_mode="zeros", align_corners=align)
+            s_ = s_.view(N, c, K, H, W).permute(0, 2, 1, 3, 4)                # (N,K,C,H,W)
+            if e.POOLING:
+                s_ = s_.reshape(N, 2, K // 2, c, H, W).max(1)[0]              # view(stride, K // stride, ...).max(0)
+            return s_
+
+        s1 = sample(other1)
+        s2 = s1 if other1 is other2 else sample(other2)
+        Ks = s1.shape[1]
+        qe = q.unsqueeze(1)
+        if e.ATTENTION == "max":                                              # :282-286: always cosine, no mask / soft-max
+            sim = F.cosine_similarity(qe.expand(-1, Ks, -1, -1, -1), s1, 2)
+        else:
+            if e.SIMILARITY == "prior":                                       # :288-289
+                sim = torch.stack([self.prior[(int(a), int(b))].to(q) for a, b in zip(camera, other_camera)])
+            else:
+                if e.SIMILARITY == "cos":
+                    sim = F.cosine_similarity(qe.expand(-1, Ks, -1, -1, -1), s1, 2)
+                else:
+                    sim = (s1 * qe).sum(2)                                    # :294-295
+                sim = sim.masked_fill(sim == 0, -1e10)                        # :298
+                pr = None
+                if e.PRIOR:
+                    pr = torch.stack([self.prior[(int(a), int(b))].to(sim) for a, b in zip(camera, other_camera)])
+                    if not e.PRIORMUL:
+                        sim = sim + pr                                        # :300-301
+                if e.SOFTMAX_ENABLED:
+                    sim = F.softmax(sim * e.SOFTMAXSCALE, 1)                  # :303-307
+                    if e.PRIORMUL:
+                        sim = sim * pr                                        # :308-309
+                else:
+                    sim = sim / Ks                                            # :310-311
+        idx = sim.argmax(1)                                                   # (N,H,W)   :225 / :237
+        with torch.no_grad():
+            gl = locs.permute(1, 0, 2, 3, 4)                                  # (N,K,H,W,2)
+            pos = torch.gather(gl, 1, idx.view(N, 1, H, W, 1).expand(-1, -1, -1, -1, 2)).squeeze(1)
+            if self.cfg.EPIPOLAR.USE_CORRECT_NORMALIZE:                       # multiview.py:39-57
+                corr_pos = torch.stack([(pos[..., 0] + 1) * (W - 1) / 2, (pos[..., 1] + 1) * (H - 1) / 2], -1)
+            else:
+                corr_pos = torch.stack([(pos[..., 0] + 1) * W / 2 - 0.5, (pos[..., 1] + 1) * H / 2 - 0.5], -1)
+        if e.ATTENTION == "max":                                              # :232-235
+            c2 = s2.shape[2]
+            out = torch.gather(s2, 1, idx.view(N, 1, 1, H, W).expand(-1, -1, c2, -1, -1)).squeeze(1)
+        else:
+            out = (s2 * sim.unsqueeze(2)).sum(1)                              # :243
+        return out, sim, corr_pos
 
     # --------------------------------------------------------------- forward
     host_P = None    # optional (P_ref_cpu, P_src_cpu) of the CURRENT batch, set by a launcher that still has the data
@@ -153,8 +233,12 @@ class Epipolar(nn.Module):
             # the fused kernels never materialise it
             raise NotImplementedError("Epipolar(debug=True): the 9-tuple of geometry intermediates is not produced by "
                                       "the fused path; use VIS.EPIPOLAR_LINE for sample_locs")
-        out, attn, corr_pos = self.attend(feat1, feat2, P1, P2)
-        if self._eval_fast_path((feat1, feat2)) and "z" in self.cfg.EPIPOLAR.PARAMETERIZED:
+        fused = self._fused_mode(ref1, ref2)
+        if fused:
+            out, attn, corr_pos = self.attend(feat1, feat2, P1, P2)
+        else:
+            out, attn, corr_pos = self._attend_general(feat1, feat2, P1, P2, camera, other_camera, ref1, ref2)
+        if fused and self._eval_fast_path((feat1, feat2)) and "z" in self.cfg.EPIPOLAR.PARAMETERIZED:
             # one GEMM (hipBLASLt, fp32 MFMA) with the bias in its epilogue
             wt, bf = self._folded_z()
             o = ops.to_nhwc(out)
@@ -167,11 +251,14 @@ class Epipolar(nn.Module):
             sample_locs = ops.sample_locs(self.layer_spec(), cam).transpose(0, 1)   # (K,N,H,W,2) -> epipolar.py:267
         return finalout, corr_pos, attn, sample_locs
 
-    def forward_fused(self, feat1, feat2, P1, P2):
+    def forward_fused(self, feat1, feat2, P1, P2, camera=None, other_camera=None):
         """forward + `ret + feat` (resnet.py:388).  In eval mode the whole epilogue is ONE GEMM: the fused
         kernel also emits feat + bf while the reference row is in registers, and
         x = (feat + bf) + out @ Wf^T accumulates into it.  Returns (x, corr_pos, depth, None)."""
         self._check_mode(None, None, None)
+        if not self._fused_mode():
+            fin, corr_pos, attn, _ = self.forward(feat1, feat2, P1, P2, camera=camera, other_camera=other_camera)
+            return fin + feat1, corr_pos, attn, None                         # resnet.py:388
         if not self._eval_fast_path((feat1, feat2)):
             out, attn, corr_pos = self.attend(feat1, feat2, P1, P2)
             _, x = self._epilogue_torch(out, feat1)

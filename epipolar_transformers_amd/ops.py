@@ -269,6 +269,22 @@ def residual_epilogue(feat, out, y=None, scale=None, shift=None, want_finalout=T
     return fin, x
 
 
+def heatmap_peaks(heatmaps: torch.Tensor, radius: float, downsample: float, threshold: float = 1e-6,
+                  legacy_floor_division: bool = False):
+    """find_tensor_peak_batch for a whole batch in ONE kernel: heatmaps (N,J,H,W) -> locations (N,J,2) in image
+    coordinates and scores (N,J).  No gradient (the reference's locations are only used for evaluation)."""
+    _require_gpu(heatmaps, "heatmaps")
+    n, j, h, w = heatmaps.shape
+    hm = heatmaps.detach().contiguous()
+    locs = torch.empty((n, j, 2), dtype=torch.float32, device=hm.device)
+    scores = torch.empty((n, j), dtype=torch.float32, device=hm.device)
+    with torch.cuda.device(hm.device):
+        _lib.check(_lib.load().et_heatmap_peaks(n * j, h, w, _ptr(hm), float(radius), float(downsample), float(threshold),
+                                                int(bool(legacy_floor_division)), _ptr(locs), _ptr(scores), _stream(hm)),
+                   "et_heatmap_peaks")
+    return locs, scores
+
+
 class EpipolarAttend(torch.autograd.Function):
     """out = sum_k softmax_k(scale * mask(f_ref . S_k)) S_k with S_k the K bilinear
     samples of f_src on the pixel's epipolar segment (epipolar.py:188-247).

@@ -177,6 +177,16 @@ int et_residual_epilogue(int64_t num_pixels, int32_t C, const float *feat, const
                          const float *y, const float *scale, const float *shift, float *finalout,
                          float *x, void *stream);
 
+/* Peak finder of the pose head: find_tensor_peak_batch (modeling/backbones/basic_batch.py:17-63), which
+ * PoseResNet.forward calls once per sample in a Python loop (resnet.py:424-430).  One launch for all maps.
+ *   heatmaps : (num_maps, H, W) float32, num_maps = N * joints (the NCHW output of final_layer as it lies in memory)
+ *   radius   : cfg.KEYPOINT.SIGMA ;  downsample : cfg.BACKBONE.DOWNSAMPLE ;  threshold : 1e-6 in the reference
+ *   legacy_floor_division : index / W as integer division (torch < 1.5, what the authors trained with) instead of
+ *                           the true division the torch of this image performs
+ *   locs     : (num_maps, 2) image coordinates (x, y) ;  scores : (num_maps) the maximum of each map */
+int et_heatmap_peaks(int64_t num_maps, int32_t H, int32_t W, const float *heatmaps, float radius, float downsample,
+                     float threshold, int32_t legacy_floor_division, float *locs, float *scores, void *stream);
+
 /* Layout converters between the reference's NCHW and the kernels' NHWC. */
 int et_nchw_to_nhwc(int32_t N, int32_t C, int32_t H, int32_t W, const float *src, float *dst, void *stream);
 int et_nhwc_to_nchw(int32_t N, int32_t C, int32_t H, int32_t W, const float *src, float *dst, void *stream);

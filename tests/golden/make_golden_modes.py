@@ -1,0 +1,99 @@
+"""Golden vectors for the operator's NON-headline branches, from the REAL reference.
+
+    python tests/golden/make_golden_modes.py
+
+Writes tests/golden/modes/<name>.npz: inputs, the reference module's parameters (incl. the unregistered `prior`
+tables), the reference's per-pair camera algebra on this machine, and its outputs in eval mode
+(finalout, corr_pos, depth) plus autograd gradients of sum(finalout * grad_out) w.r.t. both feature maps.
+Runs only in the build container (needs /root/reference)."""
+import os
+import sys
+import warnings
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from oracle import oracle as orc  # noqa: E402
+from oracle import ref_harness as rh  # noqa: E402
+from epipolar_transformers_amd import synthetic as syn  # noqa: E402
+
+H, IMAGE = 16, 64
+CASES = [
+    # configs/epipolar/keypoint_h36m_param.yaml: theta / phi / g bottleneck + POOLING, z without residual
+    dict(name="param_pool_c16_k16", C=16, K=16, ov=["EPIPOLAR.PARAMETERIZED", "('z', 'theta', 'phi', 'g')",
+                                                     "EPIPOLAR.POOLING", "True", "EPIPOLAR.BOTTLENECK", "2",
+                                                     "EPIPOLAR.ZRESIDUAL", "False"]),
+    dict(name="attention_max_c8_k8", C=8, K=8, ov=["EPIPOLAR.ATTENTION", "max", "EPIPOLAR.PARAMETERIZED", "('z',)",
+                                                   "EPIPOLAR.ZRESIDUAL", "True"]),
+    dict(name="cosine_c8_k8", C=8, K=8, ov=["EPIPOLAR.SIMILARITY", "cos", "EPIPOLAR.PARAMETERIZED", "('z',)",
+                                            "EPIPOLAR.ZRESIDUAL", "True"]),
+    dict(name="prior_add_c8_k8", C=8, K=8, ov=["EPIPOLAR.PRIOR", "True", "DATASETS.CAMERAS", "(1, 2, 3, 4)",
+                                               "EPIPOLAR.PARAMETERIZED", "()"]),
+    dict(name="prior_mul_c8_k8", C=8, K=8, ov=["EPIPOLAR.PRIOR", "True", "EPIPOLAR.PRIORMUL", "True",
+                                               "DATASETS.CAMERAS", "(1, 2, 3, 4)", "EPIPOLAR.PARAMETERIZED", "()"]),
+    dict(name="rgb_corr_c8_k8", C=8, K=8, ov=["EPIPOLAR.FIND_CORR", "rgb", "EPIPOLAR.OTHER_GRAD", "('other2',)",
+                                              "EPIPOLAR.PARAMETERIZED", "()"]),
+]
+
+
+def run_case(c):
+    ov = ["KEYPOINT.HEATMAP_SIZE", "(%d, %d)" % (H, H), "KEYPOINT.NFEATS", str(c["C"]), "EPIPOLAR.SAMPLESIZE", str(c["K"]),
+          "DATASETS.IMAGE_SIZE", "(%d, %d)" % (IMAGE, IMAGE), "EPIPOLAR.USE_CORRECT_NORMALIZE", "True"] + c["ov"]
+    mod, cfg = rh.reference_epipolar(overrides=ov)
+    seed = sum(map(ord, c["name"])) % 1000
+    P1, P2 = syn.make_pairs(1, 4, IMAGE, seed=seed, jitter=(0.05, 3.0))
+    N = P1.shape[0]
+    f1, f2 = syn.make_features(N, c["C"], H, H, seed=seed)
+    f1[0, :, 3, 5] = 0.0
+    g = torch.Generator().manual_seed(seed + 1)
+    with torch.no_grad():
+        for p in mod.parameters():
+            p.normal_(0, 0.2, generator=g)
+        if hasattr(mod, "bn"):
+            mod.bn.weight.normal_(1, 0.1, generator=g)
+            mod.bn.running_mean.normal_(0, 0.1, generator=g)
+            mod.bn.running_var.uniform_(0.5, 1.5, generator=g)
+    camera = torch.tensor([1, 2, 3, 4])
+    other_camera = torch.tensor([2, 3, 4, 1])
+    rgb1 = torch.rand(N, 3, H, H, generator=g)
+    rgb2 = torch.rand(N, 3, H, H, generator=g)
+    kw = dict(camera=camera, other_camera=other_camera)
+    if "rgb" in c["name"]:
+        kw.update(ref1=rgb1, ref2=rgb2)
+    mod.eval()
+    a1, a2 = f1.clone().requires_grad_(True), f2.clone().requires_grad_(True)
+    fin, corr_pos, depth, _ = mod(a1, a2, P1, P2, **kw)
+    grad_out = torch.randn(fin.shape, generator=g)
+    (fin * grad_out).sum().backward()
+    a, b, e = orc.camera_algebra(P1, P2)
+    cam = np.concatenate([a.reshape(N, 12), b.reshape(N, 12), e.reshape(N, 3)], 1).astype(np.float32)
+    npf = lambda t: t.detach().numpy().astype(np.float32)
+    data = dict(feat1=npf(f1), feat2=npf(f2), P1=npf(P1), P2=npf(P2), cam=cam, grad_out=npf(grad_out),
+                camera=camera.numpy(), other_camera=other_camera.numpy(), rgb1=npf(rgb1), rgb2=npf(rgb2),
+                finalout=npf(fin), corr_pos=npf(corr_pos), depth=npf(depth),
+                grad_feat1=npf(a1.grad) if a1.grad is not None else np.zeros_like(npf(f1)),
+                grad_feat2=npf(a2.grad) if a2.grad is not None else np.zeros_like(npf(f2)),
+                overrides=np.array(c["ov"]), meta=np.array([H, c["C"], c["K"], N, IMAGE], np.int64))
+    for k, v in mod.state_dict().items():
+        data["sd." + k] = npf(v) if v.dtype.is_floating_point else v.numpy()
+    for (i, j), v in getattr(mod, "prior", {}).items():
+        data["prior.%d.%d" % (i, j)] = npf(v)
+    return data
+
+
+def main():
+    warnings.simplefilter("ignore")
+    torch.set_num_threads(4)
+    outdir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "modes")
+    os.makedirs(outdir, exist_ok=True)
+    for c in CASES:
+        data = run_case(c)
+        path = os.path.join(outdir, c["name"] + ".npz")
+        np.savez_compressed(path, **data)
+        print("%-28s %7.1f KiB" % (c["name"], os.path.getsize(path) / 1024))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,124 @@
+"""Model level on the GPU (SURVEY.md 8f rows N1 / N3 and EPIPOLAR.MULTITEST): trunk once per view, GPU lifting."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _cfg(**over):
+    from epipolar_transformers_amd import default_cfg
+
+    size, hs = 64, 16
+    cfg = default_cfg()
+    cfg.merge_from_list(["BACKBONE.BODY", "epipolarposeR-18", "BACKBONE.PRETRAINED", False, "DATASETS.TASK", "multiview_keypoint",
+                         "KEYPOINT.HEATMAP_SIZE", (hs, hs), "KEYPOINT.NUM_PTS", 17, "KEYPOINT.SIGMA", 2.0,
+                         "DATASETS.IMAGE_SIZE", (size, size), "EPIPOLAR.MERGE", "late", "EPIPOLAR.ATTENTION", "avg",
+                         "EPIPOLAR.PARAMETERIZED", ("z",), "EPIPOLAR.ZRESIDUAL", True, "EPIPOLAR.USE_CORRECT_NORMALIZE", True,
+                         "EPIPOLAR.SAMPLESIZE", 16, "VIS.MULTIVIEW", True])
+    for k, v in over.items():
+        cfg.merge_from_list([k, v])
+    return cfg, size, hs
+
+
+def _model(cfg):
+    from epipolar_transformers_amd.model import MultiViewPoseModel
+
+    torch.manual_seed(11)
+    m = MultiViewPoseModel(cfg).cuda().eval()
+    with torch.no_grad():
+        m.reference.epipolar_sampler.bn.weight.normal_(1, 0.1)
+        m.reference.epipolar_sampler.bn.bias.normal_(0, 0.1)
+    return m
+
+
+def test_trunk_once_per_view_equals_the_two_pass_reference_form():
+    """N1: forward_views (trunk once per view) gives exactly what the reference's two passes give in eval mode:
+    backbone(other_img) for the source features, then reference(img, [other_features, ...]) (model.py:241-247)."""
+    from epipolar_transformers_amd import synthetic as syn
+    from epipolar_transformers_amd.model import ring_sources
+
+    cfg, size, hs = _cfg()
+    m = _model(cfg)
+    frames, V = 2, 4
+    P = torch.from_numpy(syn.ring_cameras(V, size)).float().repeat(frames, 1, 1)            # frame-major (F*V,3,4)
+    img = torch.randn(frames * V, 3, size, size, device="cuda")
+    src = ring_sources(frames, V, "cuda")
+    with torch.no_grad():
+        one = m.forward_views(img, P, src)
+        other_features = m.backbone(img[src])[0]
+        two = m.reference(img, [other_features, P[src.cpu()], None, P, None, None, None])
+    assert torch.equal(one[0], two[0])                                   # pre-fusion features
+    assert (one[1][0] - two[1][0]).abs().max().item() <= 1e-5            # heat maps
+    assert (one[2] - two[2]).abs().max().item() <= 1e-3 and torch.equal(one[4], two[4]) and torch.equal(one[5], two[5])
+    # dict form = Modelbuilder.forward: both spellings of the batch, plus lifting and MPJPE on the device
+    gt = torch.randn(frames, V, 17, 3, device="cuda").double()
+    metrics, out = m({"img": img, "KRT": P, "other_index": src, "points-3d": gt, "num_views": V}, is_train=False)
+    metrics2, out2 = m({"img": img, "KRT": P, "other_img": img[src], "other_KRT": P[src.cpu()], "num_views": V}, is_train=False)
+    assert out["points-3d"].is_cuda and tuple(out["points-3d"].shape) == (frames, 17, 3) and "MPJPE" in metrics
+    assert (out["batch_locs"] - out2["batch_locs"]).abs().max().item() <= 1e-3
+    # training: the reference's loss entry, gradients reach the trunk and the layer
+    m.train()
+    loss, _ = m({"img": img, "KRT": P, "other_index": src, "heatmap": torch.rand(frames * V, 17, hs, hs, device="cuda"),
+                 "visibility": torch.ones(frames * V, 17, 1, device="cuda"), "num_views": V}, is_train=True)
+    loss["stage_loss0"].backward()
+    assert m.reference.conv1.weight.grad is not None and m.reference.epipolar_sampler.z.weight.grad is not None
+
+
+def test_multitest_picks_the_best_source_per_joint():
+    """EPIPOLAR.MULTITEST (model.py:213-239): every other view as the source; per joint the highest score wins."""
+    from epipolar_transformers_amd import synthetic as syn
+
+    cfg, size, hs = _cfg(**{"EPIPOLAR.MULTITEST": True})
+    m = _model(cfg)
+    frames, V = 1, 4
+    P = torch.from_numpy(syn.ring_cameras(V, size)).float()
+    img = torch.randn(V, 3, size, size, device="cuda")
+    with torch.no_grad():
+        locs, scos = m.forward_multitest(img, P, V)
+        all_l, all_s = [], []
+        for shift in range(1, V):                                           # the reference's loop over other views
+            idx = torch.arange(V, device="cuda").roll(-shift)
+            of = m.backbone(img[idx])[0]
+            r = m.reference(img, [of, P[idx.cpu()], None, P, None, None, None])
+            all_l.append(r[2])
+            all_s.append(r[3])
+        all_l, all_s = torch.stack(all_l), torch.stack(all_s)
+        best, which = all_s.max(0)
+        want = torch.gather(all_l, 0, which[None, ..., None].expand(-1, -1, -1, 2)).squeeze(0)
+    assert (best - scos).abs().max().item() <= 1e-5 and (want - locs).abs().max().item() <= 1e-3
+
+
+def test_lifting_on_device_matches_the_reference_linear_triangulation():
+    """N3: `lift` (batched float64 SVD-DLT on the GPU) against a per-joint numpy restatement of the reference's
+    find3d (vision/multi_camera_system.py:199-225) with the confidence rule of triangulation.py:427-435."""
+    from epipolar_transformers_amd import synthetic as syn
+    from epipolar_transformers_amd.triangulate import triangulate_dlt
+
+    V, J, F_ = 4, 17, 3
+    P = torch.from_numpy(syn.ring_cameras(V, 256))                       # (V,3,4) float64
+    g = torch.Generator().manual_seed(2)
+    X = torch.tensor([0.0, 0.0, 900.0], dtype=torch.float64) + torch.randn(F_, J, 3, generator=g, dtype=torch.float64) * 300
+    Xh = torch.cat([X, torch.ones(F_, J, 1, dtype=torch.float64)], -1)
+    uvw = torch.einsum("vij,fkj->fvki", P, Xh)
+    uv = uvw[..., :2] / uvw[..., 2:3] + torch.randn(F_, V, J, 2, generator=g, dtype=torch.float64) * 0.5   # noisy detections
+    conf = torch.rand(F_, V, J, generator=g)
+    conf[0, :, 0] = torch.tensor([0.9, 0.01, 0.8, 0.02])                # one joint with only two confident views
+    conf[1, :, 1] = 0.01                                                 # and one below the threshold everywhere
+    got = triangulate_dlt(uv.cuda(), P[None].expand(F_, -1, -1, -1).cuda(), conf.cuda(), conf_thres=0.05).cpu().numpy()
+    Pn, uvn, cn = P.numpy(), uv.numpy(), conf.double().numpy()
+    for f in range(F_):
+        for k in range(J):
+            thr = 0.05
+            while True:
+                sel = np.where(cn[f, :, k] > thr)[0]
+                if thr < -1 or len(sel) > 1:
+                    break
+                thr -= 0.05
+            A = []
+            for v in sel:
+                A.append(uvn[f, v, k, 0] * Pn[v, 2] - Pn[v, 0])
+                A.append(uvn[f, v, k, 1] * Pn[v, 2] - Pn[v, 1])
+            _, _, vt = np.linalg.svd(np.array(A))
+            want = vt[-1, :3] / vt[-1, 3]
+            assert np.abs(got[f, k] - want).max() <= 1e-6 * max(1.0, np.abs(want).max()), (f, k)

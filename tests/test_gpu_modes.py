@@ -1,0 +1,86 @@
+"""The operator's non-headline branches on the GPU against outputs of the REAL reference
+(tests/golden/modes/*.npz, made by tests/golden/make_golden_modes.py): theta/phi/g bottleneck + POOLING
+(configs/epipolar/keypoint_h36m_param.yaml), ATTENTION max, cosine similarity, PRIOR (+PRIORMUL), FIND_CORR rgb."""
+import glob
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN_DIR
+
+pytestmark = pytest.mark.gpu
+
+MODES = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN_DIR, "modes", "*.npz")))
+
+
+def _module(d):
+    from epipolar_transformers_amd import default_cfg
+    from epipolar_transformers_amd.epipolar import Epipolar
+
+    H, C, K, N, image = [int(v) for v in d["meta"]]
+    cfg = default_cfg()
+    cfg.merge_from_list(["KEYPOINT.HEATMAP_SIZE", (H, H), "KEYPOINT.NFEATS", C, "EPIPOLAR.SAMPLESIZE", K,
+                         "DATASETS.IMAGE_SIZE", (image, image), "EPIPOLAR.USE_CORRECT_NORMALIZE", True] +
+                        [str(v) for v in d["overrides"]])
+    mod = Epipolar(cfg=cfg).cuda().eval()
+    sd = {k[3:]: torch.from_numpy(d[k]) for k in d.files if k.startswith("sd.")}
+    assert sorted(mod.state_dict()) == sorted(sd), (sorted(mod.state_dict()), sorted(sd))   # same keys as the reference module
+    mod.load_state_dict(sd)
+    for k in d.files:
+        if k.startswith("prior."):
+            _, i, j = k.split(".")
+            with torch.no_grad():
+                mod.prior[(int(i), int(j))] = torch.nn.Parameter(torch.from_numpy(d[k]).cuda())
+    cam = torch.from_numpy(d["cam"]).cuda()
+    mod._cams.get = lambda *a, **k: cam                        # the algebra the reference computed for the fixture
+    return mod
+
+
+@pytest.mark.parametrize("name", MODES)
+def test_mode_vs_reference(name):
+    d = np.load(os.path.join(GOLDEN_DIR, "modes", name + ".npz"))
+    mod = _module(d)
+    assert not mod._fused_mode(torch.zeros(1) if "rgb" in name else None, None)
+    dev = lambda k: torch.from_numpy(d[k]).cuda()
+    f1, f2 = dev("feat1").requires_grad_(True), dev("feat2").requires_grad_(True)
+    kw = dict(camera=torch.from_numpy(d["camera"]), other_camera=torch.from_numpy(d["other_camera"]))
+    if "rgb" in name:
+        kw.update(ref1=dev("rgb1"), ref2=dev("rgb2"))
+    fin, corr, depth, _ = mod(f1, f2, torch.from_numpy(d["P1"]), torch.from_numpy(d["P2"]), **kw)
+    assert tuple(fin.shape) == d["finalout"].shape and tuple(depth.shape) == d["depth"].shape
+    scale = max(1.0, float(np.abs(d["finalout"]).max()))
+    assert np.abs(fin.detach().cpu().numpy() - d["finalout"]).max() <= 1e-4 * scale
+    assert np.abs(depth.detach().cpu().numpy() - d["depth"]).max() <= 1e-5 * max(1.0, float(np.abs(d["depth"]).max()))
+    neq = (corr.cpu().numpy() != d["corr_pos"]).any(-1)
+    assert neq.mean() <= 2e-2                                  # arg-max ties (checked strictly on the fused path)
+    (fin * dev("grad_out")).sum().backward()
+    for got, want in ((f1.grad, d["grad_feat1"]), (f2.grad, d["grad_feat2"])):
+        got = np.zeros_like(want) if got is None else got.cpu().numpy()
+        assert np.abs(got - want).max() <= 1e-4 * max(float(np.abs(want).max()), 1e-6)
+
+
+def test_param_yaml_runs_through_the_backbone():
+    """`configs/epipolar/keypoint_h36m_param.yaml` semantics through epipolarposeR-50 (the one shipped epipolar YAML
+    that used to raise NotImplementedError)."""
+    from epipolar_transformers_amd import backbones, default_cfg, synthetic as syn
+
+    size, hs = 64, 16
+    cfg = default_cfg()
+    cfg.merge_from_list(["BACKBONE.BODY", "epipolarposeR-50", "BACKBONE.PRETRAINED", False,
+                         "KEYPOINT.HEATMAP_SIZE", (hs, hs), "KEYPOINT.NUM_PTS", 20, "KEYPOINT.SIGMA", 2.0,
+                         "DATASETS.IMAGE_SIZE", (size, size), "EPIPOLAR.MERGE", "late", "EPIPOLAR.ATTENTION", "avg",
+                         "EPIPOLAR.PARAMETERIZED", ("z", "theta", "phi", "g"), "EPIPOLAR.POOLING", True,
+                         "EPIPOLAR.BOTTLENECK", 2, "EPIPOLAR.ZRESIDUAL", False, "EPIPOLAR.SAMPLESIZE", 16])
+    net = backbones.build_backbone(cfg).cuda().eval()
+    assert {"epipolar_sampler.theta.weight", "epipolar_sampler.phi.weight", "epipolar_sampler.g.weight",
+            "epipolar_sampler.z.weight"} <= set(net.state_dict())
+    assert tuple(net.epipolar_sampler.z.weight.shape) == (256, 128, 1, 1)
+    P1, P2 = syn.make_pairs(1, 4, size, seed=2, jitter=(0.03, 2.0))
+    img = torch.randn(4, 3, size, size, device="cuda")
+    with torch.no_grad():
+        src = net(img.roll(-1, 0))[0]
+        feat, heat, locs, scos, corr, depth, sl, _ = net(img, [src, P2, None, P1, None, None, None])
+    assert tuple(heat[0].shape) == (4, 20, hs, hs) and tuple(depth.shape) == (4, 8, hs, hs)      # K / 2 pooled samples
+    assert torch.isfinite(heat[0]).all() and tuple(locs.shape) == (4, 20, 2)
