@@ -14,7 +14,7 @@ for step in "$@"; do
     smoke)
       echo "== smoke"; timeout 600 python -c "import __graft_entry__ as g; g.smoke()" > "$OUT/smoke_$TAG.log" 2>&1; echo "smoke exit $?"; tail -3 "$OUT/smoke_$TAG.log";;
     pytest)
-      echo "== pytest gpu"; timeout 1500 python -m pytest tests -m gpu -q --timeout 600 -x > "$OUT/pytest_gpu_$TAG.log" 2>&1; echo "pytest exit $?"; tail -30 "$OUT/pytest_gpu_$TAG.log";;
+      echo "== pytest gpu"; timeout 1500 python -m pytest tests -m gpu -q --timeout 600 > "$OUT/pytest_gpu_$TAG.log" 2>&1; echo "pytest exit $?"; tail -30 "$OUT/pytest_gpu_$TAG.log";;
     bench)
       echo "== bench"; timeout 900 python bench.py --steps 30 --warmup 5 > "$OUT/bench_$TAG.json" 2> "$OUT/bench_$TAG.err"; echo "bench exit $?"
       cat "$OUT/bench_$TAG.json"; tail -5 "$OUT/bench_$TAG.err";;

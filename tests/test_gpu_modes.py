@@ -22,8 +22,11 @@ def _module(d):
     H, C, K, N, image = [int(v) for v in d["meta"]]
     cfg = default_cfg()
     cfg.merge_from_list(["KEYPOINT.HEATMAP_SIZE", (H, H), "KEYPOINT.NFEATS", C, "EPIPOLAR.SAMPLESIZE", K,
-                         "DATASETS.IMAGE_SIZE", (image, image), "EPIPOLAR.USE_CORRECT_NORMALIZE", True] +
-                        [str(v) for v in d["overrides"]])
+                         "DATASETS.IMAGE_SIZE", (image, image), "EPIPOLAR.USE_CORRECT_NORMALIZE", True,
+                         # the fixtures start from configs/epipolar/keypoint_h36m_zresidual_fixed.yaml (:27-35) ...
+                         "EPIPOLAR.ATTENTION", "avg", "EPIPOLAR.PARAMETERIZED", ("z",), "EPIPOLAR.ZRESIDUAL", True,
+                         "EPIPOLAR.MERGE", "late", "EPIPOLAR.SHARE_WEIGHTS", True] +
+                        [str(v) for v in d["overrides"]])     # ... plus the case's own overrides
     mod = Epipolar(cfg=cfg).cuda().eval()
     sd = {k[3:]: torch.from_numpy(d[k]) for k in d.files if k.startswith("sd.")}
     assert sorted(mod.state_dict()) == sorted(sd), (sorted(mod.state_dict()), sorted(sd))   # same keys as the reference module
