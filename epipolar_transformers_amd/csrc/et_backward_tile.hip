@@ -11,7 +11,7 @@ extern "C" {
 
 size_t et_epipolar_backward_tiled_workspace_bytes(const EtLayerDesc *desc)
 {
-    if (validate(desc) || !tile_eligible(desc) || desc->K > 64) return 0;
+    if (validate(desc) || !tile_eligible(desc)) return 0;
     return et_epipolar_forward_workspace_bytes(desc);
 }
 
@@ -25,7 +25,7 @@ int et_epipolar_backward_tiled(const EtLayerDesc *desc, const float *xs, const f
         return fail("et_epipolar_backward_tiled: NULL pointer");
     const size_t need = et_epipolar_backward_tiled_workspace_bytes(desc);
     if (need == 0)
-        return fail("et_epipolar_backward_tiled: needs C == 256, K <= 64, H*W <= 16384 and 4 min(K, max(W,H)) <= %d "
+        return fail("et_epipolar_backward_tiled: needs C == 256, H*W <= 16384 and 4 min(K, max(W,H)) <= %d "
                     "(got C=%d H=%d W=%d K=%d); use et_epipolar_backward", tile_rows_cap(desc), desc->C, desc->H,
                     desc->W, desc->K);
     if (!workspace || workspace_bytes < need)
@@ -63,19 +63,30 @@ int et_epipolar_backward_tiled(const EtLayerDesc *desc, const float *xs, const f
                        tp.tiles_per_pair * kTilePix, perm, (int *)nullptr);
     if (int e = check_launch("et_epipolar_backward_tiled(order)")) return e;
     const int rows = tile_rows(desc);
+    const int kpl = (desc->K + 63) / 64;
     const size_t lds = (size_t)(tile_array_floats(rows) + rows + kTilePix + 4 + kTilePix * 4) * 4 +
-                       (size_t)tp.hw_words * 8 + (size_t)kTilePix * kWave * 8;
-#define ET_BTILE(RR)                                                                                            \
+                       (size_t)tp.hw_words * 8 + (kpl == 1 ? (size_t)kTilePix * kWave * 8 : 0);
+#define ET_BTILE(KK, RR)                                                                                        \
     do {                                                                                                        \
         if (lds > 48 * 1024) {                                                                                  \
-            hipError_t ae = hipFuncSetAttribute(reinterpret_cast<const void *>(epipolar_bwd_tile_kernel<RR>),   \
+            hipError_t ae = hipFuncSetAttribute(reinterpret_cast<const void *>(epipolar_bwd_tile_kernel<KK, RR>), \
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);          \
             if (ae != hipSuccess) return fail("hipFuncSetAttribute(bwd tile kernel): %s", hipGetErrorString(ae)); \
         }                                                                                                       \
-        hipLaunchKernelGGL((epipolar_bwd_tile_kernel<RR>), dim3((unsigned)total), dim3(256), lds, st, tp);      \
+        hipLaunchKernelGGL((epipolar_bwd_tile_kernel<KK, RR>), dim3((unsigned)total), dim3(256), lds, st, tp);  \
     } while (0)
-    if (rows == kTileRowsSmall) ET_BTILE(kTileRowsSmall);
-    else ET_BTILE(kTileRowsLarge);
+    if (rows == kTileRowsSmall) {
+        if (kpl == 1) ET_BTILE(1, kTileRowsSmall);
+        else if (kpl == 2) ET_BTILE(2, kTileRowsSmall);
+        else ET_BTILE(4, kTileRowsSmall);
+    } else if (rows == kTileRowsLarge) {
+        if (kpl == 1) ET_BTILE(1, kTileRowsLarge);
+        else if (kpl == 2) ET_BTILE(2, kTileRowsLarge);
+        else ET_BTILE(4, kTileRowsLarge);
+    } else {
+        if (kpl == 2) ET_BTILE(2, kTileRowsHuge);   // (512 rows per pixel need K > 96)
+        else ET_BTILE(4, kTileRowsHuge);
+    }
 #undef ET_BTILE
     return check_launch("et_epipolar_backward_tiled");
 }

@@ -218,7 +218,7 @@ _BWD_EXPLICIT = _lib.ET_VARIANT_BWD_ATOMIC | _lib.ET_VARIANT_BWD_UNSORTED | _lib
 def backward_nhwc(spec: LayerSpec, ref, src, cam, grad_out, use_workspace=True, form=None):
     """d(feat_ref), d(feat_src) of forward_nhwc.  Three forms of the same gradient:
       "tile"    MFMA tile formulation, d(feat_src) accumulated with float atomics across tiles: fastest,
-                reproducible to rounding only (C == 256, K <= 64);
+                reproducible to rounding only (C == 256, K <= 256);
       "gather"  per-(pixel,row) coefficients -> counting sort -> ordered per-row sums: no float atomics, bit-reproducible;
       "atomic"  bilinear-transpose scatter with float atomics (no workspace).
     form=None picks "tile" where it applies (unless the spec's variant names a backward form or NO_TILE), else
@@ -243,7 +243,7 @@ def backward_nhwc(spec: LayerSpec, ref, src, cam, grad_out, use_workspace=True, 
     with torch.cuda.device(ref.device):
         if form == "tile":
             if tile_bytes == 0:
-                raise _lib.EpipolarAmdError("the tiled backward needs C == 256 and K <= 64 (got C=%d, K=%d)" % (c, spec.K))
+                raise _lib.EpipolarAmdError("the tiled backward needs the 256-channel head (got C=%d, K=%d, %dx%d)" % (c, spec.K, h, w))
             ws = _workspace(ref.device, tile_bytes, "fwd")
             _lib.check(lib.et_epipolar_backward_tiled(*args, _ptr(ws), ctypes.c_size_t(tile_bytes), _stream(ref)),
                        "et_epipolar_backward_tiled")

@@ -154,7 +154,7 @@ int et_epipolar_backward(const EtLayerDesc *desc, const float *xs, const float *
                          const float *grad_out, float *grad_ref, float *grad_src, void *workspace,
                          size_t workspace_bytes, void *stream);
 
-/* The backward in the same MFMA tile formulation (C == 256, K <= 64): per 32-pixel tile the similarity and
+/* The backward in the same MFMA tile formulation (C == 256, K <= 256): per 32-pixel tile the similarity and
  * g.S_k come from two GEMMs against the tile's source rows, d(feat_ref) from a third, and d(feat_src) from
  * two pixel-contracting GEMMs whose U x C results are added into grad_src with float atomics (grad_src is
  * zero-filled first).  ~50x fewer atomics than the scatter form and ~3x faster than the gather form, but the

@@ -147,7 +147,7 @@ def test_layerspec_constants_match_reference_constructor():
 def test_tile_path_eligibility_is_decided_on_the_host(lib):
     """et_epipolar_forward_workspace_bytes / et_epipolar_backward_tiled_workspace_bytes run on the host: they say
     which shapes take the MFMA tile kernels (C == 256, H*W <= 16384, one pixel's rows 4*min(K, max(W,H)) within the
-    256-, 384- or 512-row tile array; the backward also needs K <= 64) and size the per-pair pixel-order scratch."""
+    256-, 384- or 512-row tile array) and size the per-pair pixel-order scratch."""
     import ctypes
 
     from epipolar_transformers_amd import ops
@@ -167,9 +167,9 @@ def test_tile_path_eligibility_is_decided_on_the_host(lib):
     d = ops.LayerSpec(H=64, W=64, K=64).desc(3, 256)
     assert int(lib.et_epipolar_forward_workspace_stats_offset(ctypes.byref(d))) == (3 * 128 * 32 + 64 + 3 * 128) * 4
     assert sizes(64, 64, 64, 128) == (0, 0)                 # other channel counts: per-pixel kernels
-    f5, b5 = sizes(128, 128, 128, 256)                      # config 5: 512-row tiles, forward only (K > 64)
-    assert f5 == ws_bytes(3 * 512) and b5 == 0
+    f5, b5 = sizes(128, 128, 128, 256)
+    assert f5 == b5 == ws_bytes(3 * 512)                    # config 5: 512-row tiles, K = 128 (two samples per lane)
     assert sizes(129, 128, 16, 256) == (0, 0)               # more than 16384 pixels per pair
     f, b = sizes(32, 32, 128, 256)
-    assert f > 0 and b == 0                                 # K > 64: tiled forward only
+    assert f > 0 and b == f                                 # K > 64: both tile kernels (K <= 256)
     assert sizes(16, 16, 16, 256, variant=32768)[0] > 0 and sizes(64, 64, 64, 256, variant=32768) == (0, 0)
