@@ -60,7 +60,7 @@ def parse():
                     help="also time epipolarposeR-50 end to end (trunk once per view + layer + head + peaks); not the headline value")
     ap.add_argument("--cpu-pairs", type=int, default=128, help="pairs in the bounded CPU-baseline sample")
     ap.add_argument("--cpu-reps", type=int, default=1)
-    ap.add_argument("--cpu-ref-pairs", type=int, default=16, help="pairs timed through the reference's op sequence")
+    ap.add_argument("--cpu-ref-pairs", type=int, default=8, help="pairs timed through the reference's op sequence")
     return ap.parse_args()
 
 
@@ -295,6 +295,7 @@ def end_to_end(args, dev, P_ref, P_src, frames, V):
                          "KEYPOINT.NFEATS", args.channels, "DATASETS.IMAGE_SIZE", (args.hw * 4, args.hw * 4),
                          "EPIPOLAR.MERGE", "late", "EPIPOLAR.ATTENTION", "avg", "EPIPOLAR.PARAMETERIZED", ("z",),
                          "EPIPOLAR.ZRESIDUAL", True, "EPIPOLAR.USE_CORRECT_NORMALIZE", True,
+                         "EPIPOLAR.SHARE_WEIGHTS", True,          # every configs/epipolar/*.yaml of the reference sets it
                          "EPIPOLAR.SAMPLESIZE", args.samples])
     net = MultiViewPoseModel(cfg).to(dev).eval().to(memory_format=torch.channels_last)
     n = frames * V

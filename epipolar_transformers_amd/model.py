@@ -64,7 +64,7 @@ class MultiViewPoseModel(nn.Module):
         """All views of a batch at once.  img (M,3,Hi,Wi), KRT (M,3,4), source_index (M,) = row of the source view of
         every row.  Returns the backbone's 8-tuple (resnet.py:437) with the trunk run once per view."""
         net = self.reference
-        other_KRT = KRT[source_index.to(KRT.device)]
+        other_KRT = KRT[source_index.to(KRT.device)]            # KRT on the host: pass a host index to avoid a sync
         if self.cfg.EPIPOLAR.MERGE != "late" or self.backbone is not self.reference:
             with torch.set_grad_enabled(torch.is_grad_enabled() and bool(self.cfg.EPIPOLAR.OTHER_GRAD)):
                 feats = self.backbone(img)[0]                               # model.py:241-244

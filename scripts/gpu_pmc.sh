@@ -21,24 +21,27 @@ do
   echo "group $i ($grp): exit $?"
 done
 python - <<PY
-import csv, glob, collections, os
+import csv, glob, collections, os, re
 out = "$OUT/pmc_${TAG}"
 agg = collections.OrderedDict()
 for f in sorted(glob.glob(out + "/g*/**/*counter_collection.csv", recursive=True)):
     for row in csv.DictReader(open(f)):
-        if "epipolar" not in row.get("Kernel_Name", ""):
+        m = re.search(r"(epipolar_\w+|tile_order_kernel)(<[^>]*>)?", row.get("Kernel_Name", ""))
+        if not m:
             continue
-        k = (row["Kernel_Name"].split("(")[0][-60:], row["Counter_Name"])
+        k = (m.group(0), row["Counter_Name"])          # per kernel (template arguments included)
         agg.setdefault(k, []).append(float(row["Counter_Value"]))
 with open(out + "_summary.txt", "w") as fh:
     for (kn, cn), vals in agg.items():
         line = "%-62s %-32s n=%d mean=%.6g" % (kn, cn, len(vals), sum(vals) / len(vals))
         print(line); fh.write(line + "\n")
 import json
-get = lambda name: next((sum(v) / len(v) for (kn, cn), v in agg.items() if cn == name), None)
+main = ([kn for kn, _ in agg if "ws_kernel" in kn] + [kn for kn, _ in agg if "bwd_tile" in kn or "fwd_tile_kernel" in kn] +
+        [kn for kn, _ in agg if kn.startswith("epipolar")] + [None])[0]          # the dominant kernel of the run
+get = lambda name: next((sum(v) / len(v) for (kn, cn), v in agg.items() if cn == name and kn == main), None)
 if get("FETCH_SIZE") is not None and get("WRITE_SIZE") is not None:
     json.dump({"C": 256, "H": int(os.environ.get("PROF_HW", 64)), "W": int(os.environ.get("PROF_HW", 64)),
-               "K": int(os.environ.get("PROF_K", 64)), "pairs": 128, "kernel": os.environ.get("PROF_KERNEL", "fwd"),
+               "K": int(os.environ.get("PROF_K", 64)), "pairs": 128, "kernel": main,
                "variant": int(os.environ.get("PROF_VARIANT", 0)), "FETCH_SIZE_KB": get("FETCH_SIZE"),
                "WRITE_SIZE_KB": get("WRITE_SIZE"), "TCC_HIT_sum": get("TCC_HIT_sum"), "TCC_MISS_sum": get("TCC_MISS_sum"),
                "VALUBusy": get("VALUBusy"), "SQ_INSTS_VALU": get("SQ_INSTS_VALU")},

@@ -1,0 +1,55 @@
+#!/bin/bash
+# Round profiles on the GPU box (via gpurun): every number DESIGN.md / README.md quote comes from a file this writes.
+# usage: gpu_profiles.sh TAG      -> gpurun_out/<TAG>_*   (copy what is to be judged into profiles/)
+ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
+cd "$ROOT"
+OUT="$ROOT/gpurun_out"; mkdir -p "$OUT"
+TAG=${1:-r02}
+export HSA_ENABLE_IPC_MODE_LEGACY=0
+stats() {  # stats NAME -- bench args...   : rocprofv3 --kernel-trace --stats of a bench run, keep the kernel_stats csv
+  local name=$1; shift
+  (cd /tmp && export TMPDIR=/tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_${TAG}_$name" -o trace -- \
+      python "$ROOT/bench.py" "$@" > "$OUT/${TAG}_${name}_rocprof.log" 2>&1)
+  local f=$(find "$OUT/prof_${TAG}_$name" -name "*kernel_stats.csv" | head -1)
+  [ -n "$f" ] && cp "$f" "$OUT/${TAG}_${name}_kernel_stats.csv" && head -6 "$f"
+  rm -rf "$OUT/prof_${TAG}_$name"
+}
+echo "== bench (configs[1])"; timeout 900 python bench.py --steps 30 --warmup 5 --end-to-end > "$OUT/${TAG}_bench.json" 2> "$OUT/${TAG}_bench.err"; tail -c 600 "$OUT/${TAG}_bench.json"; echo
+echo "== bench classic (exact fp32 one-block-per-tile kernel)"; timeout 600 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --variant 65536 > "$OUT/${TAG}_bench_variant65536_classic_fp32.json" 2>> "$OUT/${TAG}_bench.err"
+echo "== bench per-pixel"; timeout 600 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --variant 16384 > "$OUT/${TAG}_bench_variant16384_perpixel.json" 2>> "$OUT/${TAG}_bench.err"
+echo "== bench config4 head (96x96, K=64, 128 pairs)"; timeout 600 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --hw 96 > "$OUT/${TAG}_bench_config4.json" 2>> "$OUT/${TAG}_bench.err"
+echo "== bench config5 share (128x128, K=128, 8 views x 8 frames = 64 pairs)"; timeout 600 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --samples 128 --hw 128 --frames 8 --views 8 > "$OUT/${TAG}_bench_config5.json" 2>> "$OUT/${TAG}_bench.err"
+python - <<PY
+import json
+for n in ("bench", "bench_variant65536_classic_fp32", "bench_variant16384_perpixel", "bench_config4", "bench_config5"):
+    try:
+        r = json.load(open("$OUT/${TAG}_%s.json" % n))
+        print("%-36s step %.3f ms  fwd %.3f ms  bwd %.3f ms  %.0f pair-views/s" % (n, r["ms_per_step"], r["extra"]["fused_kernel_fwd_ms"], r["extra"]["fused_kernel_bwd_ms"], r["value"]), r["extra"].get("end_to_end", ""))
+    except Exception as e:
+        print(n, "failed", e)
+PY
+echo "== rocprof kernel stats"
+stats bench --steps 10 --warmup 3 --no-cpu-baseline
+stats config4 --steps 5 --warmup 2 --no-cpu-baseline --hw 96
+stats config5 --steps 5 --warmup 2 --no-cpu-baseline --samples 128 --hw 128 --frames 8 --views 8
+echo "== residual epilogue kernel"
+(cd /tmp && export TMPDIR=/tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_${TAG}_epi" -o trace -- python - <<PY > "$OUT/${TAG}_epilogue_rocprof.log" 2>&1
+import sys, torch
+sys.path.insert(0, "$ROOT")
+from epipolar_transformers_amd import ops
+shape = (128, 64, 64, 256)
+feat, out, y = (torch.randn(shape, device="cuda") for _ in range(3))
+sc, sh = torch.randn(256, device="cuda"), torch.randn(256, device="cuda")
+for _ in range(10):
+    ops.residual_epilogue(feat, out, y, sc, sh, want_finalout=False, want_x=True)     # 4 tensors x 537 MB
+    ops.residual_epilogue(feat, out, want_finalout=False, want_x=True)                 # 3 tensors
+torch.cuda.synchronize()
+PY
+)
+f=$(find "$OUT/prof_${TAG}_epi" -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" "$OUT/${TAG}_epilogue_kernel_stats.csv" && head -4 "$f"; rm -rf "$OUT/prof_${TAG}_epi"
+echo "== PMC forward"; bash scripts/gpu_pmc.sh "${TAG}_fwd_tile" 0 fwd | tail -34
+echo "== PMC backward"; bash scripts/gpu_pmc.sh "${TAG}_bwd_tile" 0 bwd | tail -34
+echo "== microbenchmarks"
+for m in mfma_valu_overlap mfma_valu_samewave load_patterns; do
+  [ -x scripts/micro/$m ] && timeout 120 scripts/micro/$m > "$OUT/${TAG}_micro_$m.txt" 2>&1 && tail -3 "$OUT/${TAG}_micro_$m.txt"
+done
