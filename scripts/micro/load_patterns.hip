@@ -4,6 +4,8 @@
 //   pattern 1: fragment       lane (li, lh) reads 16 B at row R[li], byte 32 c + 16 lh    (32 rows x 32 B)
 //   pattern 2: fragment64     lane (li, lh) reads 16 B at row R[li], byte 64 c + 32 lh + {0,16} (two loads: 32 rows x 64 B)
 //   pattern 3: quarter rows   lane l: row R[l / 16], byte 256 c + 16 (l % 16)      (4 rows x 256 B)
+//   pattern 5: 16 x 64 B      lane l: row R[l % 16], byte 64 c + 16 (l / 16)        (16 rows x 64 B: a 16x16x32 MFMA operand)
+//   pattern 6: 8 x 128 B      lane l: row R[l % 8], byte 128 c + 16 (l / 8)         (8 rows x 128 B)
 //   pattern 4: 8-byte pairs   dwordx2: lanes 0-31 row A 256 B, lanes 32-63 row B 256 B (G2 pattern)
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -30,6 +32,8 @@ __global__ __launch_bounds__(256) void k(const float *map, const int *rows, int 
             else if (PAT == 1) off = rows[(base + (step / 32) * 32 + li) % nrows] * 1024 + (step % 32) * 32 + lh * 16;
             else if (PAT == 2) off = rows[(base + (step / 32) * 32 + li) % nrows] * 1024 + ((step % 32) / 2) * 64 + lh * 32 + (step & 1) * 16;
             else if (PAT == 3) off = rows[(base + (step / 4) * 4 + lane / 16) % nrows] * 1024 + (step % 4) * 256 + (lane % 16) * 16;
+            else if (PAT == 5) off = rows[(base + (step / 16) * 16 + lane % 16) % nrows] * 1024 + (step % 16) * 64 + (lane / 16) * 16;
+            else if (PAT == 6) off = rows[(base + (step / 8) * 8 + lane % 8) % nrows] * 1024 + (step % 8) * 128 + (lane / 8) * 16;
             else off = rows[(base + step * 2 + lh) % nrows] * 1024 + ((step % 4) * 64 + 2 * li) * 4;
             if (PAT == 4) {
                 const u32x2 w = __builtin_amdgcn_raw_buffer_load_b64(src, off, 0, 0);
@@ -82,6 +86,10 @@ int main()
         run<3, 8>("quarter-rows", map, rows, nrows, out, cyc, waves);
         run<3, 16>("quarter-rows", map, rows, nrows, out, cyc, waves);
         run<3, 32>("quarter-rows", map, rows, nrows, out, cyc, waves);
+        run<5, 8>("16x64B", map, rows, nrows, out, cyc, waves);
+        run<5, 32>("16x64B", map, rows, nrows, out, cyc, waves);
+        run<6, 8>("8x128B", map, rows, nrows, out, cyc, waves);
+        run<6, 32>("8x128B", map, rows, nrows, out, cyc, waves);
         run<4, 8>("pairs-8B", map, rows, nrows, out, cyc, waves);
         run<4, 32>("pairs-8B", map, rows, nrows, out, cyc, waves);
     }

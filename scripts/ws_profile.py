@@ -38,10 +38,10 @@ torch.cuda.synchronize()
 raw.et_dev_ws_profile(None)
 p = prof.cpu().numpy().reshape(256, 4 + nv, 12).astype(np.float64) / 64.0      # cycles per tile (64 tiles per block)
 m, v = p[:, :4], p[:, 4:]
-names_m = ["G1", "wait A", "G2", "prefetch", "wait B"]
+names_m = ["G2 prefetch", "wait A", "G2", "G1 prefetch", "wait B", "copy load", "G1", "matrix barrier", "copy finish"]
 names_v = ["SM tail (scatter)", "S1", "vbar", "S2", "wait A", "merge+copy+zero", "wait B", "-", "SM front", "SM softmax", "SM corr"]
 print("cycles per tile (mean over blocks; per wave index)")
 print("matrix waves: " + "  ".join("%s %s" % (n, np.round(m[:, :, k].mean(0)).astype(int).tolist()) for k, n in enumerate(names_m)))
-print("  total per tile: %s" % np.round(m[:, :, :5].sum(2).mean(0)).astype(int).tolist())
+print("  total per tile: %s" % np.round(m[:, :, :9].sum(2).mean(0)).astype(int).tolist())
 print("vector waves: " + "  ".join("%s %s" % (n, np.round(v[:, :, k].mean(0)).astype(int).tolist()) for k, n in enumerate(names_v)))
 print("  total per tile: %s" % np.round(v.sum(2).mean(0)).astype(int).tolist())
