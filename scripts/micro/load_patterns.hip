@@ -6,6 +6,7 @@
 //   pattern 3: quarter rows   lane l: row R[l / 16], byte 256 c + 16 (l % 16)      (4 rows x 256 B)
 //   pattern 5: 16 x 64 B      lane l: row R[l % 16], byte 64 c + 16 (l / 16)        (16 rows x 64 B: a 16x16x32 MFMA operand)
 //   pattern 6: 8 x 128 B      lane l: row R[l % 8], byte 128 c + 16 (l / 8)         (8 rows x 128 B)
+//   pattern 7: 16 x 64 B, quad-contiguous   lane l: row R[l / 4], byte 64 c + 16 (l % 4)
 //   pattern 4: 8-byte pairs   dwordx2: lanes 0-31 row A 256 B, lanes 32-63 row B 256 B (G2 pattern)
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -34,6 +35,7 @@ __global__ __launch_bounds__(256) void k(const float *map, const int *rows, int 
             else if (PAT == 3) off = rows[(base + (step / 4) * 4 + lane / 16) % nrows] * 1024 + (step % 4) * 256 + (lane % 16) * 16;
             else if (PAT == 5) off = rows[(base + (step / 16) * 16 + lane % 16) % nrows] * 1024 + (step % 16) * 64 + (lane / 16) * 16;
             else if (PAT == 6) off = rows[(base + (step / 8) * 8 + lane % 8) % nrows] * 1024 + (step % 8) * 128 + (lane / 8) * 16;
+            else if (PAT == 7) off = rows[(base + (step / 16) * 16 + lane / 4) % nrows] * 1024 + (step % 16) * 64 + (lane % 4) * 16;
             else off = rows[(base + step * 2 + lh) % nrows] * 1024 + ((step % 4) * 64 + 2 * li) * 4;
             if (PAT == 4) {
                 const u32x2 w = __builtin_amdgcn_raw_buffer_load_b64(src, off, 0, 0);
@@ -66,8 +68,40 @@ void run(const char *name, const float *map, const int *rows, int nrows, float *
     printf("%-14s %d waves/CU, %2d loads in flight per wave: %.1f cycles of CU time per instruction, %.1f B/clk/CU\n", name, waves, NF,
            m / iters / NF / waves, (PAT == 4 ? 512.0 : 1024.0) * waves / (m / iters / NF));
 }
+__global__ __launch_bounds__(256) void kperm(int iters, int *out, long long *cyc)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int addr = (4 * (lane & 15) + (lane >> 4)) * 4;
+    int v[8];
+    for (int r = 0; r < 8; ++r) v[r] = lane * 7 + r;
+    const long long t0 = __builtin_amdgcn_s_memtime();
+    for (int i = 0; i < iters; ++i) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) v[r] = __builtin_amdgcn_ds_bpermute(addr, v[r]);
+    }
+    const long long t1 = __builtin_amdgcn_s_memtime();
+    int s = 0;
+    for (int r = 0; r < 8; ++r) s += v[r];
+    out[blockIdx.x * 256 + threadIdx.x] = s;
+    if (lane == 0) cyc[blockIdx.x * 4 + wave] = t1 - t0;
+}
 int main()
 {
+    {
+        int *o; long long *c;
+        hipMalloc(&o, 256 * 256 * 4); hipMalloc(&c, 1024 * 8);
+        for (int waves : {1, 4}) {
+            kperm<<<256, 64 * waves>>>(2000, o, c); hipDeviceSynchronize();
+            kperm<<<256, 64 * waves>>>(2000, o, c); hipDeviceSynchronize();
+            std::vector<long long> h(1024);
+            hipMemcpy(h.data(), c, 1024 * 8, hipMemcpyDeviceToHost);
+            double m = 0;
+            for (int b = 0; b < 256; ++b) for (int w = 0; w < waves; ++w) m += h[b * 4 + w];
+            m /= 256.0 * waves;
+            printf("ds_bpermute_b32, %d waves/CU, 8 independent per wave: %.1f cycles per instruction per wave, %.1f cycles of CU time\n",
+                   waves, m / 2000 / 8, m / 2000 / 8 / waves);
+        }
+    }
     float *map, *out; int *rows; long long *cyc;
     hipMalloc(&map, 4096u * 1024u); hipMemset(map, 0, 4096u * 1024u);
     hipMalloc(&out, 256 * 256 * 4); hipMalloc(&cyc, 1024 * 8);
@@ -90,6 +124,8 @@ int main()
         run<5, 32>("16x64B", map, rows, nrows, out, cyc, waves);
         run<6, 8>("8x128B", map, rows, nrows, out, cyc, waves);
         run<6, 32>("8x128B", map, rows, nrows, out, cyc, waves);
+        run<7, 8>("16x64B quads", map, rows, nrows, out, cyc, waves);
+        run<7, 32>("16x64B quads", map, rows, nrows, out, cyc, waves);
         run<4, 8>("pairs-8B", map, rows, nrows, out, cyc, waves);
         run<4, 32>("pairs-8B", map, rows, nrows, out, cyc, waves);
     }
