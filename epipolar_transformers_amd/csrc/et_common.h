@@ -273,9 +273,21 @@ __device__ __forceinline__ float4 buf_load_f4(__amdgpu_buffer_rsrc_t r, int voff
     return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
 }
 
+// streaming variant (read once: marked non-temporal so it does not push the re-used source rows out of L2)
+__device__ __forceinline__ float4 buf_load_f4_nt(__amdgpu_buffer_rsrc_t r, int voff, int soff)
+{
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 2);
+    return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+}
+
 __device__ __forceinline__ float buf_load_f1(__amdgpu_buffer_rsrc_t r, int voff, int soff)
 {
     return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
+}
+
+__device__ __forceinline__ float buf_load_f1_nt(__amdgpu_buffer_rsrc_t r, int voff, int soff)
+{
+    return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 2));
 }
 
 __device__ __forceinline__ f32x2 buf_load_f2(__amdgpu_buffer_rsrc_t r, int voff, int soff)

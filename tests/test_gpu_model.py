@@ -78,26 +78,30 @@ def test_multitest_picks_the_best_source_per_joint():
     img = torch.randn(V, 3, size, size, device="cuda")
     with torch.no_grad():
         locs, scos = m.forward_multitest(img, P, V)
-        all_l, all_s, own_l, own_s = [], [], [], []
+        all_s = []
         for shift in range(1, V):                                           # the reference's loop over other views
             idx = torch.arange(V, device="cuda").roll(-shift)
             of = m.backbone(img[idx])[0]
-            r = m.reference(img, [of, P[idx.cpu()], None, P, None, None, None])
-            all_l.append(r[2])
-            all_s.append(r[3])
-            r = m.forward_views(img, P, idx)                                # same trunk batch as forward_multitest
+            all_s.append(m.reference(img, [of, P[idx.cpu()], None, P, None, None, None])[3])
+        best, _ = torch.stack(all_s).max(0)
+        # scores against the reference's two-pass loop
+        assert (best - scos).abs().max().item() <= 1e-3
+        # Locations: a random-initialised head gives nearly flat heat maps whose arg-max flips on the 1e-4 differences
+        # between two runs of the MIOpen trunk, so the per-joint selection is checked with the trunk output frozen:
+        # single-source passes and the one-launch form then see identical features (the fused layer is batch-invariant
+        # bit for bit) and must agree exactly.
+        feat = m.reference.trunk(img)
+        m.reference.trunk = lambda x: feat
+        locs, scos = m.forward_multitest(img, P, V)
+        own_l, own_s = [], []
+        for shift in range(1, V):
+            r = m.forward_views(img, P, torch.arange(V, device="cuda").roll(-shift))
             own_l.append(r[2])
             own_s.append(r[3])
-        best, _ = torch.stack(all_s).max(0)
         own_best, which = torch.stack(own_s).max(0)
         want = torch.gather(torch.stack(own_l), 0, which[None, ..., None].expand(-1, -1, -1, 2)).squeeze(0)
-    # scores against the reference's two-pass loop.  Locations: a random-initialised head gives nearly flat heat maps,
-    # whose arg-max flips on the 1e-4 differences between two runs of the MIOpen trunk on differently composed
-    # batches -- so the per-joint selection is checked against single-source passes over the SAME trunk batch (the
-    # fused layer is batch-invariant bit for bit), where it must agree exactly.
-    assert (best - scos).abs().max().item() <= 1e-3
-    assert (own_best - scos).abs().max().item() <= 1e-5
-    assert (want - locs).abs().max().item() <= 1e-3
+    assert (own_best - scos).abs().max().item() <= 1e-6
+    assert (want - locs).abs().max().item() <= 1e-4
 
 
 def test_lifting_on_device_matches_the_reference_linear_triangulation():

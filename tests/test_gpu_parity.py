@@ -690,3 +690,25 @@ def test_heatmap_peaks_kernel(env, shape, radius, legacy):
     got_l, got_s = ops.heatmap_peaks(hm, radius, 4, legacy_floor_division=legacy)
     assert torch.equal(got_s, want_s)
     assert (got_l - want_l).abs().max().item() <= 2e-3, (got_l - want_l).abs().max().item()      # image pixels
+
+
+def test_split_fp16_guard_outliers_fall_back_to_exact_fp32(env):
+    """The warp-specialised forward computes its two GEMMs as split-fp16 products under per-pair power-of-two scales
+    ESTIMATED from 64 sampled pixel rows (column 0 of every image row at 64x64).  A value outside the sample that the
+    scale would push beyond fp16's range must send its tiles to the exact-fp32 kernel -- in the reference rows
+    (checked where the A stage is written) and in the source rows (checked by GEMM 1) -- never produce inf / NaN."""
+    _lib, camera, ops = env
+    P1, P2, f1, f2 = _full_inputs(1, 4, 64, 256, 256, seed=3)
+    cam = camera.pair_algebra(P1, P2).cuda()
+    ref, src = ops.to_nhwc(f1.cuda()).contiguous(), ops.to_nhwc(f2.cuda()).contiguous()
+    ref[0, 10, 11, 5] = 4e4            # ~2^18 x the sampled maximum after scaling: beyond fp16
+    src[1, 40, 3, 100] = 4e4
+    src[2, 17, 29, 7] = -6e4
+    bias = torch.randn(256, device="cuda")
+    got = ops.forward_nhwc(ops.LayerSpec(H=64, W=64, K=64), ref, src, cam, res_bias=bias, want_res_base=True)
+    want = ops.forward_nhwc(ops.LayerSpec(H=64, W=64, K=64, variant=_lib.ET_VARIANT_NO_TILE), ref, src, cam,
+                            res_bias=bias, want_res_base=True)
+    for g, w, atol in zip(got, want, (1e-4, 1e-5, 0.0, 0.0)):
+        g, w = g.float(), w.float()
+        assert torch.isfinite(g).all()
+        assert ((g - w).abs() - 1e-5 * w.abs()).max().item() <= atol
