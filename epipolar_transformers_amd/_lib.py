@@ -32,7 +32,7 @@ ET_VARIANT_TILE_SPLIT = 32768
 ET_VARIANT_TILE_CLASSIC = 65536
 ET_VARIANT_WS_NV4 = 131072
 ET_VARIANT_WS_SETPRIO = 262144
-ET_ABI_VERSION = 6
+ET_ABI_VERSION = 7
 
 
 class EpipolarAmdError(RuntimeError):
@@ -69,6 +69,9 @@ _SIGNATURES = {
     "et_epipolar_backward_workspace_bytes": (ctypes.c_size_t, [_D]),
     "et_epipolar_backward": (ctypes.c_int, [_D, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, ctypes.c_size_t, _P]),
     "et_residual_epilogue": (ctypes.c_int, [ctypes.c_int64, ctypes.c_int32, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "et_residual_gemm_packed_bytes": (ctypes.c_size_t, []),
+    "et_residual_gemm_pack": (ctypes.c_int, [_P, _P, _P]),
+    "et_residual_gemm": (ctypes.c_int, [ctypes.c_int64, ctypes.c_int32, _P, _P, _P, _P, _P, _P]),
     "et_heatmap_peaks": (ctypes.c_int, [ctypes.c_int64, ctypes.c_int32, ctypes.c_int32, _P, ctypes.c_float, ctypes.c_float,
                                         ctypes.c_float, ctypes.c_int32, _P, _P, _P]),
     "et_nchw_to_nhwc": (ctypes.c_int, [ctypes.c_int32] * 4 + [_P, _P, _P]),

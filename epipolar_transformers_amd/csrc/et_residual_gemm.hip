@@ -1,0 +1,50 @@
+// libepipolar_amd.so: the eval-mode residual fusion as one GEMM (C = 256) -- et_residual_gemm_pack, et_residual_gemm.
+#include "et_common.h"
+
+namespace {
+#include "et_wave_reduce.h"
+#include "kernels_residual_gemm.inc"
+}  // namespace
+
+extern "C" {
+
+size_t et_residual_gemm_packed_bytes(void) { return (size_t)kRgPackedWords * 4 + 256; }
+
+int et_residual_gemm_pack(const float *wf, void *packed, void *stream)
+{
+    if (!wf || !packed) return fail("et_residual_gemm_pack: NULL pointer");
+    if (reinterpret_cast<uintptr_t>(packed) & 15) return fail("et_residual_gemm_pack: packed buffer must be 16-byte aligned");
+    hipLaunchKernelGGL(residual_gemm_pack_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, wf,
+                       reinterpret_cast<unsigned *>(packed));
+    return check_launch("et_residual_gemm_pack");
+}
+
+int et_residual_gemm(int64_t num_pixels, int32_t C, const float *out, const float *feat, const void *packed,
+                     const float *bias, float *x, void *stream)
+{
+    if (C != 256) return fail("et_residual_gemm: C = %d (the kernel is written for the 256-channel head)", C);
+    if (num_pixels <= 0) return fail("et_residual_gemm: bad sizes");
+    if (!out || !packed || !bias || !x) return fail("et_residual_gemm: NULL pointer");
+    if (reinterpret_cast<uintptr_t>(packed) & 15) return fail("et_residual_gemm: packed buffer must be 16-byte aligned");
+    const long long blocks = (num_pixels + kRgRows - 1) / kRgRows;
+    if (blocks > 0x7fffffffLL) return fail("et_residual_gemm: too many rows");
+    hipStream_t st = (hipStream_t)stream;
+    static bool attr_done[2] = {false, false};
+    if (!attr_done[feat ? 1 : 0]) {
+        hipError_t ae = feat ? hipFuncSetAttribute(reinterpret_cast<const void *>(residual_gemm_kernel<true>),
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)kRgLdsBytes)
+                             : hipFuncSetAttribute(reinterpret_cast<const void *>(residual_gemm_kernel<false>),
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)kRgLdsBytes);
+        if (ae != hipSuccess) return fail("hipFuncSetAttribute(residual_gemm_kernel): %s", hipGetErrorString(ae));
+        attr_done[feat ? 1 : 0] = true;
+    }
+    if (feat)
+        hipLaunchKernelGGL(residual_gemm_kernel<true>, dim3((unsigned)blocks), dim3(256), kRgLdsBytes, st, out, feat,
+                           reinterpret_cast<const unsigned *>(packed), bias, x, (long long)num_pixels);
+    else
+        hipLaunchKernelGGL(residual_gemm_kernel<false>, dim3((unsigned)blocks), dim3(256), kRgLdsBytes, st, out, feat,
+                           reinterpret_cast<const unsigned *>(packed), bias, x, (long long)num_pixels);
+    return check_launch("et_residual_gemm");
+}
+
+}  // extern "C"

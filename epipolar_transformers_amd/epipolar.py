@@ -201,6 +201,19 @@ class Epipolar(nn.Module):
         bf = self.z.bias * scale + (self.bn.bias - self.bn.running_mean * scale)
         return wf.t().contiguous(), bf.contiguous()
 
+    def _packed_z(self):
+        """The folded z branch laid out for `ops.residual_gemm` (C == 256): (packed weight, bias), cached until a
+        parameter or buffer of the branch changes (their version counters / storage)."""
+        ps = (self.z.weight, self.z.bias, self.bn.weight, self.bn.bias, self.bn.running_mean, self.bn.running_var)
+        key = tuple((q.data_ptr(), q._version) for q in ps) + (bool(self.cfg.EPIPOLAR.ZRESIDUAL), float(self.bn.eps))
+        hit = getattr(self, "_packed_z_cache", None)
+        if hit is None or hit[0] != key:
+            with torch.no_grad():
+                wt, bf = self._folded_z()
+                hit = (key, ops.residual_gemm_pack(wt.t().contiguous()), bf)
+            self._packed_z_cache = hit
+        return hit[1], hit[2]
+
     def _eval_fast_path(self, tensors):
         cfg = self.cfg
         if not bool(amd_knob(cfg, "FUSED_EPILOGUE", True)):
@@ -239,10 +252,13 @@ class Epipolar(nn.Module):
         else:
             out, attn, corr_pos = self._attend_general(feat1, feat2, P1, P2, camera, other_camera, ref1, ref2)
         if fused and self._eval_fast_path((feat1, feat2)) and "z" in self.cfg.EPIPOLAR.PARAMETERIZED:
-            # one GEMM (hipBLASLt, fp32 MFMA) with the bias in its epilogue
-            wt, bf = self._folded_z()
             o = ops.to_nhwc(out)
-            finalout = torch.addmm(bf, o.reshape(-1, o.shape[-1]), wt).view_as(o).permute(0, 3, 1, 2)
+            if o.shape[-1] == 256:    # one HBM-bound kernel: bias + out . Wf^T (split-fp16 MFMA)
+                packed, bf = self._packed_z()
+                finalout = ops.residual_gemm(o, packed, bf).permute(0, 3, 1, 2)
+            else:                     # one library GEMM with the bias in its epilogue
+                wt, bf = self._folded_z()
+                finalout = torch.addmm(bf, o.reshape(-1, o.shape[-1]), wt).view_as(o).permute(0, 3, 1, 2)
         else:
             finalout, _ = self._epilogue_torch(out)
         sample_locs = None
@@ -252,9 +268,9 @@ class Epipolar(nn.Module):
         return finalout, corr_pos, attn, sample_locs
 
     def forward_fused(self, feat1, feat2, P1, P2, camera=None, other_camera=None):
-        """forward + `ret + feat` (resnet.py:388).  In eval mode the whole epilogue is ONE GEMM: the fused
-        kernel also emits feat + bf while the reference row is in registers, and
-        x = (feat + bf) + out @ Wf^T accumulates into it.  Returns (x, corr_pos, depth, None)."""
+        """forward + `ret + feat` (resnet.py:388).  In eval mode the whole epilogue is ONE GEMM kernel:
+        x = feat + bf + out @ Wf^T (`ops.residual_gemm` for the 256-channel head; other widths: the fused kernel
+        emits feat + bf and a library GEMM accumulates into it).  Returns (x, corr_pos, depth, None)."""
         self._check_mode(None, None, None)
         if not self._fused_mode():
             fin, corr_pos, attn, _ = self.forward(feat1, feat2, P1, P2, camera=camera, other_camera=other_camera)
@@ -265,7 +281,12 @@ class Epipolar(nn.Module):
             return x, corr_pos, attn, None
         cam = self._cam(P1, P2, feat1.device)
         ref, src = ops.to_nhwc(feat1), ops.to_nhwc(feat2)
-        if "z" in self.cfg.EPIPOLAR.PARAMETERIZED:
+        if "z" in self.cfg.EPIPOLAR.PARAMETERIZED and ref.shape[-1] == 256:
+            # x = feat + bf + out . Wf^T in ONE kernel behind the fused forward (no res_base round trip through HBM)
+            packed, bf = self._packed_z()
+            out, attn, corr_pos = ops.forward_nhwc(self.layer_spec(), ref, src, cam)
+            x = ops.residual_gemm(out, packed, bf, ref)
+        elif "z" in self.cfg.EPIPOLAR.PARAMETERIZED:
             wt, bf = self._folded_z()
             out, attn, corr_pos, base = ops.forward_nhwc(self.layer_spec(), ref, src, cam, res_bias=bf,
                                                          want_res_base=True)

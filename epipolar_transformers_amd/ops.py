@@ -269,6 +269,33 @@ def residual_epilogue(feat, out, y=None, scale=None, shift=None, want_finalout=T
     return fin, x
 
 
+def residual_gemm_pack(wf: torch.Tensor) -> torch.Tensor:
+    """Lay the folded (256 out, 256 in) fp32 weight of the z branch out for `residual_gemm` (split fp16 MFMA fragments +
+    the scale).  Returns the packed uint8 buffer; repack when the weights change."""
+    _require_gpu(wf, "wf")
+    assert wf.dtype == torch.float32 and tuple(wf.shape) == (256, 256), "residual_gemm is written for the 256-channel head"
+    wf = wf.contiguous()
+    lib = _lib.load()
+    packed = torch.empty(int(lib.et_residual_gemm_packed_bytes()), dtype=torch.uint8, device=wf.device)
+    with torch.cuda.device(wf.device):
+        _lib.check(lib.et_residual_gemm_pack(_ptr(wf), _ptr(packed), _stream(wf)), "et_residual_gemm_pack")
+    return packed
+
+
+def residual_gemm(out: torch.Tensor, packed: torch.Tensor, bias: torch.Tensor, feat: torch.Tensor = None) -> torch.Tensor:
+    """x = [feat +] bias + out @ Wf^T over the last dimension (256), everything (..., 256) fp32 contiguous: the
+    eval-mode `bn(z(out)) [+ out] [+ feat]` (epipolar.py:250-253, resnet.py:388) as one HBM-bound kernel."""
+    _require_gpu(out, "out")
+    c = out.shape[-1]
+    assert out.is_contiguous() and (feat is None or (feat.is_contiguous() and feat.shape == out.shape))
+    assert bias.is_cuda and bias.numel() == c and bias.is_contiguous()
+    x = torch.empty_like(out)
+    with torch.cuda.device(out.device):
+        _lib.check(_lib.load().et_residual_gemm(out.numel() // c, c, _ptr(out), _ptr(feat), _ptr(packed), _ptr(bias), _ptr(x),
+                                                _stream(out)), "et_residual_gemm")
+    return x
+
+
 def heatmap_peaks(heatmaps: torch.Tensor, radius: float, downsample: float, threshold: float = 1e-6,
                   legacy_floor_division: bool = False):
     """find_tensor_peak_batch for a whole batch in ONE kernel: heatmaps (N,J,H,W) -> locations (N,J,2) in image

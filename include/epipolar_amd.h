@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define ET_ABI_VERSION 6
+#define ET_ABI_VERSION 7
 
 /* Static description of one layer call: the cfg keys the reference reads in
  * Epipolar.__init__ (epipolar.py:12-54) and at call time (epipolar.py:303-311,
@@ -176,6 +176,19 @@ int et_epipolar_backward_tiled(const EtLayerDesc *desc, const float *xs, const f
 int et_residual_epilogue(int64_t num_pixels, int32_t C, const float *feat, const float *out,
                          const float *y, const float *scale, const float *shift, float *finalout,
                          float *x, void *stream);
+
+/* The same fusion in eval mode as ONE GEMM for the 256-channel head (replaces the reference's conv1x1 + BN +
+ * two adds, epipolar.py:250-253, resnet.py:388):
+ *     x[m, :] = [feat[m, :] +] bias + out[m, :] . Wf^T,   Wf = diag(s) W [+ I],  bias = s b + beta - mean s,
+ * s = gamma / sqrt(var + eps)  (the caller folds; Wf is (256 out, 256 in) row-major fp32).  The products run as
+ * split-fp16 MFMAs with fp32 accumulation (fp32-level error; every row of `out` is scaled by its own power of
+ * two).  et_residual_gemm_pack lays Wf out for the kernel into `packed` (et_residual_gemm_packed_bytes() bytes,
+ * 16-byte aligned; repack when the weights change).  feat nullable (then x = bias + out . Wf^T, what
+ * Epipolar.forward returns).  out / feat / x: (num_pixels, 256) fp32, x may not alias out or feat. */
+size_t et_residual_gemm_packed_bytes(void);
+int et_residual_gemm_pack(const float *wf, void *packed, void *stream);
+int et_residual_gemm(int64_t num_pixels, int32_t C, const float *out, const float *feat, const void *packed,
+                     const float *bias, float *x, void *stream);
 
 /* Peak finder of the pose head: find_tensor_peak_batch (modeling/backbones/basic_batch.py:17-63), which
  * PoseResNet.forward calls once per sample in a Python loop (resnet.py:424-430).  One launch for all maps.

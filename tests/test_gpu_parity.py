@@ -712,3 +712,32 @@ def test_split_fp16_guard_outliers_fall_back_to_exact_fp32(env):
         g, w = g.float(), w.float()
         assert torch.isfinite(g).all()
         assert ((g - w).abs() - 1e-5 * w.abs()).max().item() <= atol
+
+
+@pytest.mark.parametrize("rows", [64, 77, 1000, 4 * 64 * 64 + 13])
+@pytest.mark.parametrize("with_feat", [True, False])
+def test_residual_gemm_abi(env, rows, with_feat):
+    """et_residual_gemm (eval-mode bn(z(out)) + out [+ feat] folded into x = [feat +] bias + out . Wf^T, split-fp16 MFMA with
+    one power-of-two scale per row) against float64: fp32-GEMM-level error on every row, whatever its magnitude --
+    ragged row counts, an all-zero row, rows of 1e-6 and 3e4 times the typical size."""
+    _lib, camera, ops = env
+    g = torch.Generator(device="cuda").manual_seed(rows)
+    out = torch.randn(rows, 256, device="cuda", generator=g).relu_() * 2.5
+    out[3] *= 1e-6
+    out[5] *= 3e4
+    out[min(rows - 1, 70)] = 0
+    feat = torch.randn(rows, 256, device="cuda", generator=g) if with_feat else None
+    wf = torch.randn(256, 256, device="cuda", generator=g) * 0.05 + torch.eye(256, device="cuda")
+    bias = torch.randn(256, device="cuda", generator=g)
+    packed = ops.residual_gemm_pack(wf)
+    x = ops.residual_gemm(out, packed, bias, feat)
+    prod = out.double() @ wf.double().t()
+    want = prod + bias.double() + (feat.double() if with_feat else 0)
+    # the error of a product row scales with the magnitudes that went into it, the additive terms add one rounding each
+    bound = 4e-6 * (out.double().abs() @ wf.double().abs().t()) + 3e-7 * (want.abs() + 1)
+    assert torch.isfinite(x).all()
+    assert ((x.double() - want).abs() <= bound).all(), ((x.double() - want).abs() / bound).max().item()
+    # same error class as the fp32 library GEMM it replaces
+    lib32 = torch.addmm(bias, out, wf.t()) + (feat if with_feat else 0)
+    scale = prod.abs().amax(1, keepdim=True).clamp_min(1e-30)
+    assert ((x.double() - want).abs() / scale).max().item() <= 4 * ((lib32.double() - want).abs() / scale).max().item() + 1e-6
