@@ -41,6 +41,14 @@ m, v = p[:, :4], p[:, 4:]
 names_m = ["G2 prefetch", "wait A", "G2", "G1 prefetch", "wait B", "copy load", "G1", "matrix barrier", "copy finish"]
 names_v = ["SM tail (scatter)", "S1", "vbar", "S2", "wait A", "merge+copy+zero", "wait B", "-", "SM front", "SM softmax", "SM corr"]
 print("cycles per tile (mean over blocks; per wave index)")
+if os.environ.get("WS_PROFILE_LIGHT"):
+    ma = m[:, :, 5] + m[:, :, 6] + m[:, :, 0]; mb = m[:, :, 3]
+    va = v[:, :, 1] + v[:, :, 3]; vb = v[:, :, 0] + v[:, :, 5]
+    r = lambda a: np.round(a.mean(0)).astype(int).tolist()
+    print("matrix waves: phase A work %s  wait A %s  phase B work %s  wait B %s" % (r(ma), r(m[:, :, 1]), r(mb), r(m[:, :, 4])))
+    print("vector waves: phase A work %s  wait A %s  phase B work %s  wait B %s" % (r(va), r(v[:, :, 4]), r(vb), r(v[:, :, 6])))
+    print("  total per tile: %s" % r(m[:, :, :9].sum(2)))
+    raise SystemExit(0)
 print("matrix waves: " + "  ".join("%s %s" % (n, np.round(m[:, :, k].mean(0)).astype(int).tolist()) for k, n in enumerate(names_m)))
 print("  total per tile: %s" % np.round(m[:, :, :9].sum(2).mean(0)).astype(int).tolist())
 print("vector waves: " + "  ".join("%s %s" % (n, np.round(v[:, :, k].mean(0)).astype(int).tolist()) for k, n in enumerate(names_v)))
