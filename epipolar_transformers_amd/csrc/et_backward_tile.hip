@@ -64,7 +64,7 @@ int et_epipolar_backward_tiled(const EtLayerDesc *desc, const float *xs, const f
     if (int e = check_launch("et_epipolar_backward_tiled(order)")) return e;
     const int rows = tile_rows(desc);
     const int kpl = (desc->K + 63) / 64;
-    const size_t lds = (size_t)(tile_array_floats(rows) + rows + kTilePix + 4 + kTilePix * 4) * 4 +
+    const size_t lds = (size_t)(tile_array_floats(rows) + rows + kTilePix + 20 + kTilePix * 4) * 4 +
                        (size_t)tp.hw_words * 8 + (kpl == 1 ? (size_t)kTilePix * kWave * 8 : 0);
 #define ET_BTILE(KK, RR)                                                                                        \
     do {                                                                                                        \

@@ -1,0 +1,49 @@
+// Split-fp16 products (device code; included inside the translation units' anonymous namespace): an fp32 value times a
+// power-of-two scale is written as hi + lo in fp16 -- hi its top 11 significant bits (exact), lo the fp16 of the exact
+// remainder -- and a product a b as hi lo' + lo hi' + hi hi' on the fp16 matrix cores with fp32 accumulation: the dropped
+// lo lo' term is 2^-22 relative, i.e. fp32-GEMM-level error at a fifth of the fp32 MFMA time.
+#pragma once
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// Two scaled fp32 values -> packed fp16 hi (top 11 significant bits: conversion with round-toward-zero, exact) and
+// packed fp16 lo (fp16 of the exact remainder v - hi, taken straight off the packed hi by v_fma_mix_f32: hi * -1 + v).
+// 2.5 instructions per value with the scale multiply, against 3 for mask / subtract / two conversions.
+__device__ __forceinline__ void split_f16_pair(float v0, float v1, unsigned &hi, unsigned &lo)
+{
+    typedef __fp16 h16x2_t __attribute__((ext_vector_type(2)));
+    typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
+    hi = __builtin_bit_cast(unsigned, (h16x2_t)__builtin_amdgcn_cvt_pkrtz(v0, v1));
+    float l0, l1;
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(l0) : "v"(hi), "v"(v0));
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(l1) : "v"(hi), "v"(v1));
+    lo = __builtin_bit_cast(unsigned, f16x2_t{(_Float16)l0, (_Float16)l1});
+}
+
+// eight scaled fp32 values -> fp16 hi and lo; amax tracks the largest magnitude seen (the overflow guard)
+template <bool GUARD>
+__device__ __forceinline__ void split_f16x8(const float (&v)[8], f16x8 &hi, f16x8 &lo, float &amax)
+{
+    u32x4 h, l;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        unsigned hh, ll;
+        split_f16_pair(v[2 * i], v[2 * i + 1], hh, ll);
+        h[i] = hh;
+        l[i] = ll;
+        if (GUARD) amax = fmaxf(amax, fmaxf(fabsf(v[2 * i]), fabsf(v[2 * i + 1])));
+    }
+    hi = __builtin_bit_cast(f16x8, h);
+    lo = __builtin_bit_cast(f16x8, l);
+}
+
+// power of two that puts a magnitude mx into [2^10, 2^11) (fp16 keeps a factor 32 of head-room above it), and its
+// inverse; mx = 0 / denormal / huge are clamped to a finite pair
+__device__ __forceinline__ void pow2_scale_of(float mx, float &sc, float &inv)
+{
+    int E = (int)((__float_as_uint(mx) >> 23) & 255u);
+    E = min(max(E, 12), 250);
+    sc = __uint_as_float((unsigned)(264 - E) << 23);      // 2^(137 - E)
+    inv = __uint_as_float((unsigned)(E - 10) << 23);      // 2^(E - 137)
+}
