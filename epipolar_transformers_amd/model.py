@@ -80,12 +80,15 @@ class MultiViewPoseModel(nn.Module):
 
     def forward_multitest(self, img: torch.Tensor, KRT: torch.Tensor, num_views: int):
         """EPIPOLAR.MULTITEST (model.py:213-239): every other view of the frame as the source in turn; per joint the
-        location with the highest score.  img (F*V, ...) frame-major.  One trunk pass, ONE fused-layer launch over all
-        F*V*(V-1) (reference, source) pairs."""
+        location with the highest score.  img (F*V, ...) frame-major.  One trunk pass per network (two without
+        SHARE_WEIGHTS: the sources come from `self.backbone`), ONE fused-layer launch over all F*V*(V-1)
+        (reference, source) pairs."""
         net = self.reference
         m = img.shape[0]
         frames = m // num_views
         feature = net.trunk(img)
+        # the source features come from `self.backbone` (model.py:219): the same network only with SHARE_WEIGHTS
+        source = feature if self.backbone is net else self.backbone(img)[0]
         base = torch.arange(m, device=img.device).view(frames, num_views)
         ref_idx, src_idx = [], []
         for shift in range(1, num_views):
@@ -93,7 +96,7 @@ class MultiViewPoseModel(nn.Module):
             src_idx.append(base.roll(-shift, 1).reshape(-1))
         ref_idx, src_idx = torch.cat(ref_idx), torch.cat(src_idx)
         Kc = KRT.to("cpu")
-        x, _, _, _ = net._fuse(feature[ref_idx], net.epipolar_sampler, feature[src_idx], Kc[ref_idx.cpu()], Kc[src_idx.cpu()],
+        x, _, _, _ = net._fuse(feature[ref_idx], net.epipolar_sampler, source[src_idx], Kc[ref_idx.cpu()], Kc[src_idx.cpu()],
                                None, None)
         heat = net.final_layer(x)
         locs, scos = backbones.find_peaks(heat, self.cfg.KEYPOINT.SIGMA, self.cfg.BACKBONE.DOWNSAMPLE)

@@ -67,16 +67,19 @@ def test_trunk_once_per_view_equals_the_two_pass_reference_form():
     assert m.reference.conv1.weight.grad is not None and m.reference.epipolar_sampler.z.weight.grad is not None
 
 
-def test_multitest_picks_the_best_source_per_joint():
-    """EPIPOLAR.MULTITEST (model.py:213-239): every other view as the source; per joint the highest score wins."""
+@pytest.mark.parametrize("share", [True, False])
+def test_multitest_picks_the_best_source_per_joint(share):
+    """EPIPOLAR.MULTITEST (model.py:213-239): every other view as the source (features from `self.backbone`: the same
+    network only with SHARE_WEIGHTS); per joint the highest score wins."""
     from epipolar_transformers_amd import synthetic as syn
 
-    cfg, size, hs = _cfg(**{"EPIPOLAR.MULTITEST": True})
+    cfg, size, hs = _cfg(**{"EPIPOLAR.MULTITEST": True, "EPIPOLAR.SHARE_WEIGHTS": share})
     m = _model(cfg)
     frames, V = 1, 4
     P = torch.from_numpy(syn.ring_cameras(V, size)).float()
     img = torch.randn(V, 3, size, size, device="cuda")
     with torch.no_grad():
+        m.reference.final_layer.weight.mul_(30.0)        # (a random-initialised head is nearly flat: give it contrast)
         locs, scos = m.forward_multitest(img, P, V)
         all_s = []
         for shift in range(1, V):                                           # the reference's loop over other views
@@ -84,19 +87,25 @@ def test_multitest_picks_the_best_source_per_joint():
             of = m.backbone(img[idx])[0]
             all_s.append(m.reference(img, [of, P[idx.cpu()], None, P, None, None, None])[3])
         best, _ = torch.stack(all_s).max(0)
-        # scores against the reference's two-pass loop
-        assert (best - scos).abs().max().item() <= 1e-3
-        # Locations: a random-initialised head gives nearly flat heat maps whose arg-max flips on the 1e-4 differences
-        # between two runs of the MIOpen trunk, so the per-joint selection is checked with the trunk output frozen:
-        # single-source passes and the one-launch form then see identical features (the fused layer is batch-invariant
-        # bit for bit) and must agree exactly.
+        # scores against the reference's two-pass loop (MIOpen's fp32 trunk differs by ~1e-4 relative between two
+        # differently composed batches; the wrong network for the sources would differ by O(1))
+        assert (best - scos).abs().max().item() <= 5e-3 * max(1.0, best.abs().max().item())
+        # Locations: the arg-max of a heat map can flip on such differences, so the per-joint selection is checked
+        # with both trunks and the 1x1 head frozen: single-source passes and the one-launch form then see identical
+        # features (the fused layer is batch-invariant bit for bit) and must agree exactly.
         feat = m.reference.trunk(img)
         m.reference.trunk = lambda x: feat
-        # (MIOpen also picks its fp32 algorithm for the 1x1 head by batch size -- 12 pairs here, 4 there -- with 3e-4
-        #  differences between them: the head in float64 for this comparison)
+        if m.backbone is not m.reference:
+            feat_b = m.backbone(img)[0]
+            m.backbone.forward = lambda x, *a, **k: (feat_b,)
         fl = m.reference.final_layer
         w64, b64 = fl.weight.double().flatten(1), fl.bias.double()
-        m.reference.final_layer = lambda t: (torch.einsum("nchw,jc->njhw", t.double(), w64) + b64[None, :, None, None]).float()
+
+        class Head64(torch.nn.Module):                   # (MIOpen also picks its algorithm for the head by batch size)
+            def forward(self, t):
+                return (torch.einsum("nchw,jc->njhw", t.double(), w64) + b64[None, :, None, None]).float()
+
+        m.reference.final_layer = Head64()
         locs, scos = m.forward_multitest(img, P, V)
         own_l, own_s = [], []
         for shift in range(1, V):
@@ -105,8 +114,8 @@ def test_multitest_picks_the_best_source_per_joint():
             own_s.append(r[3])
         own_best, which = torch.stack(own_s).max(0)
         want = torch.gather(torch.stack(own_l), 0, which[None, ..., None].expand(-1, -1, -1, 2)).squeeze(0)
-    assert (own_best - scos).abs().max().item() <= 1e-6
-    assert (want - locs).abs().max().item() <= 1e-4
+    assert (own_best - scos).abs().max().item() <= 1e-5 * max(1.0, own_best.abs().max().item())
+    assert (want - locs).abs().max().item() <= 1e-3
 
 
 def test_lifting_on_device_matches_the_reference_linear_triangulation():
