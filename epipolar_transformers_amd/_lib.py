@@ -32,7 +32,7 @@ ET_VARIANT_TILE_SPLIT = 32768
 ET_VARIANT_TILE_CLASSIC = 65536
 ET_VARIANT_WS_NV4 = 131072
 ET_VARIANT_WS_SETPRIO = 262144
-ET_ABI_VERSION = 7
+ET_ABI_VERSION = 8
 
 
 class EpipolarAmdError(RuntimeError):
@@ -66,6 +66,7 @@ _SIGNATURES = {
     "et_epipolar_forward_tiled": (ctypes.c_int, [_D] + [_P] * 12 + [ctypes.c_size_t, _P]),
     "et_epipolar_backward_tiled_workspace_bytes": (ctypes.c_size_t, [_D]),
     "et_epipolar_backward_tiled": (ctypes.c_int, [_D, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, ctypes.c_size_t, _P]),
+    "et_epipolar_backward_tiled_attn": (ctypes.c_int, [_D, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, ctypes.c_size_t, _P]),
     "et_epipolar_backward_workspace_bytes": (ctypes.c_size_t, [_D]),
     "et_epipolar_backward": (ctypes.c_int, [_D, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, ctypes.c_size_t, _P]),
     "et_residual_epilogue": (ctypes.c_int, [ctypes.c_int64, ctypes.c_int32, _P, _P, _P, _P, _P, _P, _P, _P]),

@@ -20,6 +20,15 @@ int et_epipolar_backward_tiled(const EtLayerDesc *desc, const float *xs, const f
                                const float *grad_out, float *grad_ref, float *grad_src, void *workspace,
                                size_t workspace_bytes, void *stream)
 {
+    return et_epipolar_backward_tiled_attn(desc, xs, ys, steps, cam, feat_ref, feat_src, nullptr, grad_out, grad_ref,
+                                           grad_src, workspace, workspace_bytes, stream);
+}
+
+int et_epipolar_backward_tiled_attn(const EtLayerDesc *desc, const float *xs, const float *ys, const float *steps,
+                                    const float *cam, const float *feat_ref, const float *feat_src, const float *attn,
+                                    const float *grad_out, float *grad_ref, float *grad_src, void *workspace,
+                                    size_t workspace_bytes, void *stream)
+{
     if (int e = validate(desc)) return e;
     if (!xs || !ys || !steps || !cam || !feat_ref || !feat_src || !grad_out || !grad_ref || !grad_src)
         return fail("et_epipolar_backward_tiled: NULL pointer");
@@ -49,6 +58,7 @@ int et_epipolar_backward_tiled(const EtLayerDesc *desc, const float *xs, const f
     tp.rows_cap = tile_rows_cap(desc);
     int *perm = reinterpret_cast<int *>((reinterpret_cast<uintptr_t>(workspace) + 255) & ~(uintptr_t)255);
     tp.perm = perm;
+    tp.attn = attn;
     hipError_t me = hipMemsetAsync(grad_src, 0, (size_t)desc->N * HW * desc->C * sizeof(float), st);
     if (me != hipSuccess) return fail("hipMemsetAsync(grad_src): %s", hipGetErrorString(me));
     int n2 = 64;

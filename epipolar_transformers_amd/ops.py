@@ -215,14 +215,15 @@ def tile_stats(spec: LayerSpec, n: int, c: int, workspace: torch.Tensor) -> torc
 _BWD_EXPLICIT = _lib.ET_VARIANT_BWD_ATOMIC | _lib.ET_VARIANT_BWD_UNSORTED | _lib.ET_VARIANT_NO_TILE
 
 
-def backward_nhwc(spec: LayerSpec, ref, src, cam, grad_out, use_workspace=True, form=None):
+def backward_nhwc(spec: LayerSpec, ref, src, cam, grad_out, use_workspace=True, form=None, attn=None):
     """d(feat_ref), d(feat_src) of forward_nhwc.  Three forms of the same gradient:
       "tile"    MFMA tile formulation, d(feat_src) accumulated with float atomics across tiles: fastest,
                 reproducible to rounding only (C == 256, K <= 256);
       "gather"  per-(pixel,row) coefficients -> counting sort -> ordered per-row sums: no float atomics, bit-reproducible;
       "atomic"  bilinear-transpose scatter with float atomics (no workspace).
     form=None picks "tile" where it applies (unless the spec's variant names a backward form or NO_TILE), else
-    "gather"; use_workspace=False means "atomic"."""
+    "gather"; use_workspace=False means "atomic".  `attn`: the attention forward_nhwc returned for the same inputs
+    (N,K,H,W) -- the tile form then does not recompute the soft-max (one GEMM of five less); the other forms ignore it."""
     n, h, w, c = ref.shape
     xs, ys, steps = spec.constants(ref.device)
     grad_out = grad_out.contiguous()
@@ -245,8 +246,10 @@ def backward_nhwc(spec: LayerSpec, ref, src, cam, grad_out, use_workspace=True, 
             if tile_bytes == 0:
                 raise _lib.EpipolarAmdError("the tiled backward needs the 256-channel head (got C=%d, K=%d, %dx%d)" % (c, spec.K, h, w))
             ws = _workspace(ref.device, tile_bytes, "fwd")
-            _lib.check(lib.et_epipolar_backward_tiled(*args, _ptr(ws), ctypes.c_size_t(tile_bytes), _stream(ref)),
-                       "et_epipolar_backward_tiled")
+            if attn is not None:
+                assert attn.is_cuda and attn.dtype == torch.float32 and tuple(attn.shape) == (n, spec.K, h, w) and attn.is_contiguous()
+            _lib.check(lib.et_epipolar_backward_tiled_attn(*args[:7], _ptr(attn), *args[7:], _ptr(ws), ctypes.c_size_t(tile_bytes),
+                                                           _stream(ref)), "et_epipolar_backward_tiled_attn")
         else:
             ws, ws_bytes = None, 0
             if form == "gather":
@@ -327,15 +330,15 @@ class EpipolarAttend(torch.autograd.Function):
         src = to_nhwc(feat_src)
         out, attn, corr = forward_nhwc(spec, ref, src, cam)
         ctx.spec = spec
-        ctx.save_for_backward(ref, src, cam)
+        ctx.save_for_backward(ref, src, cam, attn)       # (the soft-max output, as autograd keeps it in the reference)
         ctx.mark_non_differentiable(attn, corr)
         return out.permute(0, 3, 1, 2), attn, corr
 
     @staticmethod
     def backward(ctx, grad_out, _ga, _gc):
-        ref, src, cam = ctx.saved_tensors
+        ref, src, cam, attn = ctx.saved_tensors
         g = to_nhwc(grad_out)
-        g_ref, g_src = backward_nhwc(ctx.spec, ref, src, cam, g)
+        g_ref, g_src = backward_nhwc(ctx.spec, ref, src, cam, g, attn=attn)
         need_ref, need_src = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
         return (g_ref.permute(0, 3, 1, 2) if need_ref else None,
                 g_src.permute(0, 3, 1, 2) if need_src else None, None, None)

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define ET_ABI_VERSION 7
+#define ET_ABI_VERSION 8
 
 /* Static description of one layer call: the cfg keys the reference reads in
  * Epipolar.__init__ (epipolar.py:12-54) and at call time (epipolar.py:303-311,
@@ -166,6 +166,14 @@ int et_epipolar_backward_tiled(const EtLayerDesc *desc, const float *xs, const f
                                const float *cam, const float *feat_ref, const float *feat_src,
                                const float *grad_out, float *grad_ref, float *grad_src, void *workspace,
                                size_t workspace_bytes, void *stream);
+
+/* The same with the attention the forward returned ((N,K,H,W), what autograd saves in the reference): the soft-max
+ * is not recomputed, i.e. one of the five GEMMs, its resampling and the soft-max forward are skipped.  attn may be
+ * NULL (= et_epipolar_backward_tiled). */
+int et_epipolar_backward_tiled_attn(const EtLayerDesc *desc, const float *xs, const float *ys, const float *steps,
+                                    const float *cam, const float *feat_ref, const float *feat_src,
+                                    const float *attn, const float *grad_out, float *grad_ref, float *grad_src,
+                                    void *workspace, size_t workspace_bytes, void *stream);
 
 /* Residual fusion epilogue: x = feat + out + (y * scale[c] + shift[c])
  *   (epipolar.py:250-253 with ZRESIDUAL, then resnet.py:388 `ret + feat`),

@@ -101,8 +101,13 @@ def main():
         print("  backward tile vs gather: grad_ref %.2e (scale %.2e)  grad_src %.2e (scale %.2e)" % (
             (gr_t - gr_g).abs().max().item(), gr_g.abs().max().item(), (gs_t - gs_g).abs().max().item(),
             gs_g.abs().max().item()), flush=True)
-        print("  backward: tile %.3f ms, gather %.3f ms" % (
+        attn = ops.forward_nhwc(spec, ref, src, cam)[1]
+        gr_a, gs_a = ops.backward_nhwc(spec, ref, src, cam, go, form="tile", attn=attn)
+        print("  backward tile with the forward's attention vs gather: grad_ref %.2e  grad_src %.2e" % (
+            (gr_a - gr_g).abs().max().item(), (gs_a - gs_g).abs().max().item()), flush=True)
+        print("  backward: tile %.3f ms, tile with attention %.3f ms, gather %.3f ms" % (
             timed(lambda: ops.backward_nhwc(spec, ref, src, cam, go, form="tile"), 5, 2),
+            timed(lambda: ops.backward_nhwc(spec, ref, src, cam, go, form="tile", attn=attn), 5, 2),
             timed(lambda: ops.backward_nhwc(spec, ref, src, cam, go, form="gather"), 5, 2)), flush=True)
 
 

@@ -531,11 +531,18 @@ def test_tiled_backward_masks_and_split(env):
             spec = ops.LayerSpec(H=H, W=H, K=K, variant=variant, src_grad_mask=mask)
             gr_t, gs_t = ops.backward_nhwc(spec, ref, src, cam, go, form="tile")
             gr_g, gs_g = ops.backward_nhwc(spec, ref, src, cam, go, form="gather")
-            for got, want in ((gr_t, gr_g), (gs_t, gs_g)):
+            # the same with the attention the forward returned (no soft-max recomputation; the all-masked pixel is
+            # recognised by its uniform attention) -- from the default forward and from the exact-fp32 per-pixel one
+            attn_w = ops.forward_nhwc(ops.LayerSpec(H=H, W=H, K=K), ref, src, cam)[1]
+            attn_p = ops.forward_nhwc(ops.LayerSpec(H=H, W=H, K=K, variant=_lib.ET_VARIANT_NO_TILE), ref, src, cam)[1]
+            gr_a, gs_a = ops.backward_nhwc(spec, ref, src, cam, go, form="tile", attn=attn_w)
+            gr_b, gs_b = ops.backward_nhwc(spec, ref, src, cam, go, form="tile", attn=attn_p)
+            for got, want in ((gr_t, gr_g), (gs_t, gs_g), (gr_a, gr_g), (gs_a, gs_g), (gr_b, gr_g), (gs_b, gs_g)):
                 scale = max(want.abs().max().item(), 1e-6)
                 assert (got - want).abs().max().item() <= TOL_GRAD_REL * scale, (H, K, variant, mask)
+            assert gr_a[0, 3, 5].abs().max().item() == 0 and gr_g[0, 3, 5].abs().max().item() == 0   # masked: no gradient
             if mask == 0:
-                assert gs_t.abs().max().item() == 0
+                assert gs_t.abs().max().item() == 0 and gs_a.abs().max().item() == 0
     with pytest.raises(_lib.EpipolarAmdError):               # outside the tile path: loud, no silent fallback
         ops.backward_nhwc(ops.LayerSpec(H=8, W=8, K=8), torch.zeros(1, 8, 8, 32, device="cuda"),
                           torch.zeros(1, 8, 8, 32, device="cuda"), torch.zeros(1, 27, device="cuda"),
