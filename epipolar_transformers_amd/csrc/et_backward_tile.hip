@@ -72,10 +72,14 @@ int et_epipolar_backward_tiled_attn(const EtLayerDesc *desc, const float *xs, co
     hipLaunchKernelGGL(tile_order_kernel, dim3(desc->N), dim3(1024), lds_sort, st, *desc, xs, ys, cam, n2,
                        tp.tiles_per_pair * kTilePix, perm, (int *)nullptr);
     if (int e = check_launch("et_epipolar_backward_tiled(order)")) return e;
-    const int rows = tile_rows(desc);
     const int kpl = (desc->K + 63) / 64;
-    const size_t lds = (size_t)(tile_array_floats(rows) + rows + kTilePix + 20 + kTilePix * 4) * 4 +
-                       (size_t)tp.hw_words * 8 + (kpl == 1 ? (size_t)kTilePix * kWave * 8 : 0);
+    // 64 x 64 maps, K <= 64: the merged form (two 192-column arrays, one round of atomics per tile) unless the caller
+    // asks for the one-array kernel (ET_VARIANT_TILE_CLASSIC)
+    const bool merged = tile_rows(desc) == kTileRowsSmall && kpl == 1 && !(desc->variant & ET_VARIANT_TILE_CLASSIC);
+    const int rows = merged ? kTileRowsMerged : tile_rows(desc);
+    if (merged && tp.rows_cap > kTileRowsMerged) tp.rows_cap = kTileRowsMerged;
+    const size_t lds = (size_t)(bwd_tile_array_floats(rows) + rows + kTilePix + 20 + kTilePix * 4) * 4 +
+                       (size_t)tp.hw_words * 8 + ((kpl == 1 && !merged) ? (size_t)kTilePix * kWave * 8 : 0);
 #define ET_BTILE(KK, RR)                                                                                        \
     do {                                                                                                        \
         if (lds > 48 * 1024) {                                                                                  \
@@ -85,7 +89,9 @@ int et_epipolar_backward_tiled_attn(const EtLayerDesc *desc, const float *xs, co
         }                                                                                                       \
         hipLaunchKernelGGL((epipolar_bwd_tile_kernel<KK, RR>), dim3((unsigned)total), dim3(256), lds, st, tp);  \
     } while (0)
-    if (rows == kTileRowsSmall) {
+    if (rows == kTileRowsMerged) {
+        ET_BTILE(1, kTileRowsMerged);
+    } else if (rows == kTileRowsSmall) {
         if (kpl == 1) ET_BTILE(1, kTileRowsSmall);
         else if (kpl == 2) ET_BTILE(2, kTileRowsSmall);
         else ET_BTILE(4, kTileRowsSmall);

@@ -47,3 +47,11 @@ __device__ __forceinline__ void pow2_scale_of(float mx, float &sc, float &inv)
     sc = __uint_as_float((unsigned)(264 - E) << 23);      // 2^(137 - E)
     inv = __uint_as_float((unsigned)(E - 10) << 23);      // 2^(E - 137)
 }
+
+// the same scale with its exponent capped to [-60, 60]: products of two such scales (and their inverses) stay finite
+__device__ __forceinline__ float pow2_scale_capped(float mx)
+{
+    int E = (int)((__float_as_uint(mx) >> 23) & 255u);
+    E = min(max(E, 77), 197);
+    return __uint_as_float((unsigned)(264 - E) << 23);    // 2^(137 - E)
+}
