@@ -232,6 +232,12 @@ def main():
         ops.backward_nhwc(spec, feat_ref, src, cam, gout, attn=attn_fwd)
     torch.cuda.synchronize()
     bwd_ms = (time.perf_counter() - tb) / nb * 1e3
+    torch.cuda.synchronize()
+    tb = time.perf_counter()
+    for _ in range(nb):
+        ops.backward_nhwc(spec, feat_ref, src, cam, gout)                # soft-max recomputed (no saved attention)
+    torch.cuda.synchronize()
+    bwd_recompute_ms = (time.perf_counter() - tb) / nb * 1e3
 
     # the second kernel of the step: x = feat + bf + out @ Wf^T (HBM-bound: out and feat read, x written)
     rg = None
@@ -288,7 +294,7 @@ def main():
                    "partition": args.partition, "layout": "NHWC (channels_last)", "pairs_per_gpu": n_pairs,
                    "variant": args.variant},
         "roofline": roofline,
-        "extra": {"fused_kernel_fwd_ms": kernel_ms, "fused_kernel_bwd_ms": bwd_ms,
+        "extra": {"fused_kernel_fwd_ms": kernel_ms, "fused_kernel_bwd_ms": bwd_ms, "fused_kernel_bwd_recompute_ms": bwd_recompute_ms,
                   "kernel_only_pair_views_per_s": n_pairs / (kernel_ms * 1e-3)},
     }
     if rg is not None:

@@ -75,9 +75,10 @@ int et_epipolar_backward_tiled_attn(const EtLayerDesc *desc, const float *xs, co
     const int kpl = (desc->K + 63) / 64;
     // 64 x 64 maps, K <= 64: the merged form (two 192-column arrays, one round of atomics per tile) unless the caller
     // asks for the one-array kernel (ET_VARIANT_TILE_CLASSIC)
-    const bool merged = tile_rows(desc) == kTileRowsSmall && kpl == 1 && !(desc->variant & ET_VARIANT_TILE_CLASSIC);
-    const int rows = merged ? kTileRowsMerged : tile_rows(desc);
-    if (merged && tp.rows_cap > kTileRowsMerged) tp.rows_cap = kTileRowsMerged;
+    const bool merged = (tile_rows(desc) == kTileRowsSmall || tile_rows(desc) == kTileRowsLarge) && kpl == 1 &&
+                        !(desc->variant & ET_VARIANT_TILE_CLASSIC);
+    const int rows = !merged ? tile_rows(desc) : tile_rows(desc) == kTileRowsSmall ? kTileRowsMerged : kTileRowsMergedLarge;
+    if (merged && tp.rows_cap > rows) tp.rows_cap = rows;
     const size_t lds = (size_t)(bwd_tile_array_floats(rows) + rows + kTilePix + 20 + kTilePix * 4) * 4 +
                        (size_t)tp.hw_words * 8 + ((kpl == 1 && !merged) ? (size_t)kTilePix * kWave * 8 : 0);
 #define ET_BTILE(KK, RR)                                                                                        \
@@ -91,6 +92,8 @@ int et_epipolar_backward_tiled_attn(const EtLayerDesc *desc, const float *xs, co
     } while (0)
     if (rows == kTileRowsMerged) {
         ET_BTILE(1, kTileRowsMerged);
+    } else if (rows == kTileRowsMergedLarge) {
+        ET_BTILE(1, kTileRowsMergedLarge);
     } else if (rows == kTileRowsSmall) {
         if (kpl == 1) ET_BTILE(1, kTileRowsSmall);
         else if (kpl == 2) ET_BTILE(2, kTileRowsSmall);

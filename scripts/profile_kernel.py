@@ -20,9 +20,10 @@ ref = torch.randn(128, H, H, C, device=dev, generator=g).relu_()
 src = torch.randn(128, H, H, C, device=dev, generator=g).relu_()
 cam = camera.pair_algebra(P1, P2).to(dev)
 spec = ops.LayerSpec(H=H, W=H, K=K, variant=variant)
+attn = ops.forward_nhwc(spec, ref, src, cam)[1] if which != "fwd" else None      # what autograd hands the backward
 for _ in range(int(os.environ.get("PROF_REPS", 3))):
     if which == "fwd":
         ops.forward_nhwc(spec, ref, src, cam)
     else:
-        ops.backward_nhwc(spec, ref, src, cam, ref)
+        ops.backward_nhwc(spec, ref, src, cam, ref, attn=attn)
 torch.cuda.synchronize()

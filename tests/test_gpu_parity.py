@@ -515,11 +515,12 @@ def test_tile_path_statistics_and_split(env):
 
 
 def test_tiled_backward_masks_and_split(env):
-    """The MFMA tile backward (C=256, K<=64): equals the bit-reproducible gather form to rounding for every
-    OTHER_GRAD mask, also when 64-row tiles force the pixel-group splitting (no group may run twice: d(feat_src)
-    is accumulated with atomics)."""
+    """The MFMA tile backward (C=256): equals the bit-reproducible gather form to rounding for every OTHER_GRAD mask,
+    in its merged form (Bs and B at once, one round of atomics per tile) and as the one-array kernel, also when 64-row
+    tiles force the pixel-group splitting (no group may run twice: d(feat_src) is accumulated with atomics)."""
     _lib, camera, ops = env
-    for (H, K, variant) in ((16, 16, 0), (16, 16, 32768), (24, 33, 0)):
+    # variant 0: the merged form (two arrays, one round of atomics); 65536: the one-array kernel; 32768: 64-row tiles
+    for (H, K, variant) in ((16, 16, 0), (16, 16, 65536), (16, 16, 32768), (24, 33, 0), (24, 33, 65536)):
         P1, P2 = _full_inputs(1, 4, H, 256, H * 4, seed=31)[:2]
         g = torch.Generator().manual_seed(H + K)
         ref = torch.randn(4, H, H, 256, generator=g).relu().cuda()
