@@ -36,7 +36,9 @@ with open(out + "_summary.txt", "w") as fh:
         line = "%-62s %-32s n=%d mean=%.6g" % (kn, cn, len(vals), sum(vals) / len(vals))
         print(line); fh.write(line + "\n")
 import json
-main = ([kn for kn, _ in agg if "ws_kernel" in kn] + [kn for kn, _ in agg if "bwd_tile" in kn or "fwd_tile_kernel" in kn] +
+want_bwd = os.environ.get("PROF_KERNEL", "fwd") != "fwd"                     # (the backward run launches one forward for the attention)
+main = ([kn for kn, _ in agg if want_bwd and "bwd" in kn] + [kn for kn, _ in agg if "ws_kernel" in kn] +
+        [kn for kn, _ in agg if "bwd_tile" in kn or "fwd_tile_kernel" in kn] +
         [kn for kn, _ in agg if kn.startswith("epipolar")] + [None])[0]          # the dominant kernel of the run
 get = lambda name: next((sum(v) / len(v) for (kn, cn), v in agg.items() if cn == name and kn == main), None)
 if get("FETCH_SIZE") is not None and get("WRITE_SIZE") is not None:
