@@ -54,6 +54,25 @@ def test_validation_errors_are_reported(lib):
     assert rc != 0 and b"NULL" in lib.et_last_error()
 
 
+def test_empty_and_out_of_range_shapes_are_errors_not_silent(lib):
+    """An empty batch makes the reference raise (`torch.stack` of nothing, epipolar.py:248); here every entry point
+    reports it -- as it does K outside [2, 256], more than 512 channels, maps of 2 GiB -- before touching the GPU."""
+    null = ctypes.c_void_p(0)
+    for kw, msg in ((dict(N=0, C=8), b"bad shape"), (dict(N=1, C=516), b"> 512"), (dict(N=1, C=8, K=1), b"K=1"),
+                    (dict(N=1, C=8, K=300), b"K=300")):
+        d = ops.LayerSpec(H=8, W=8, K=kw.pop("K", 8)).desc(**kw)
+        assert lib.et_epipolar_forward(ctypes.byref(d), *[null] * 12) != 0 and msg in lib.et_last_error()
+        assert lib.et_epipolar_backward(ctypes.byref(d), *[null] * 10, ctypes.c_size_t(0), null) != 0 and msg in lib.et_last_error()
+        assert lib.et_sample_locs(ctypes.byref(d), *[null] * 6) != 0 and msg in lib.et_last_error()
+        assert int(lib.et_epipolar_forward_workspace_bytes(ctypes.byref(d))) == 0          # no tile path either
+    # the GEMM form of the residual fusion: only the 256-channel head, no NULL operands, aligned weight buffer
+    assert lib.et_residual_gemm(ctypes.c_int64(64), 128, *[null] * 6) != 0 and b"256-channel" in lib.et_last_error()
+    assert lib.et_residual_gemm(ctypes.c_int64(0), 256, *[null] * 6) != 0 and b"bad sizes" in lib.et_last_error()
+    assert lib.et_residual_gemm(ctypes.c_int64(64), 256, *[null] * 6) != 0 and b"NULL" in lib.et_last_error()
+    assert lib.et_residual_gemm_pack(null, null, null) != 0 and b"NULL" in lib.et_last_error()
+    assert int(lib.et_residual_gemm_packed_bytes()) == 16 * 8 * 2 * 64 * 16 + 256
+
+
 def test_cpu_tensors_are_rejected_not_silently_computed():
     spec = ops.LayerSpec(H=8, W=8, K=8)
     x = torch.zeros(1, 8, 8, 8)
