@@ -69,8 +69,12 @@ int et_epipolar_backward_tiled_attn(const EtLayerDesc *desc, const float *xs, co
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_sort);
         if (ae != hipSuccess) return fail("hipFuncSetAttribute(tile_order_kernel): %s", hipGetErrorString(ae));
     }
+    // (with the per-pair scale estimates of the source maps: the merged kernels run their row-type GEMMs as split-fp16
+    //  products; the workspace has the forward's layout)
+    const TileWorkspace w = carve_tile_workspace(workspace, (size_t)total, (size_t)desc->N);
+    tp.scales = w.scales;
     hipLaunchKernelGGL(tile_order_kernel, dim3(desc->N), dim3(1024), lds_sort, st, *desc, xs, ys, cam, n2,
-                       tp.tiles_per_pair * kTilePix, perm, (int *)nullptr);
+                       tp.tiles_per_pair * kTilePix, perm, (int *)nullptr, feat_ref, feat_src, w.scales, (float4 *)nullptr);
     if (int e = check_launch("et_epipolar_backward_tiled(order)")) return e;
     const int kpl = (desc->K + 63) / 64;
     // 64 x 64 maps, K <= 64: the merged form (two 192-column arrays, one round of atomics per tile) unless the caller

@@ -55,3 +55,6 @@ __device__ __forceinline__ float pow2_scale_capped(float mx)
     E = min(max(E, 77), 197);
     return __uint_as_float((unsigned)(264 - E) << 23);    // 2^(137 - E)
 }
+
+// a scaled value must stay below this for the split (fp16 max 65504): the guard of kernels that scale by an ESTIMATE
+constexpr float kF16GuardLimit = 32768.f;
