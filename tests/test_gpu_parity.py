@@ -550,6 +550,30 @@ def test_tiled_backward_masks_and_split(env):
                           torch.zeros(1, 8, 8, 32, device="cuda"), form="tile")
 
 
+def test_tiled_backward_split_gemm_guard_redoes_overflowing_tiles_in_fp32(env):
+    """The merged tile backward runs its D-type GEMMs as split-fp16 products under a per-pair scale ESTIMATED from
+    sampled pixels (every fourth pixel at 16 x 16); a source value outside the sample that the scale pushes beyond fp16
+    makes the block redo the tile's GEMM in exact fp32 -- gradients still equal the gather form, never inf / NaN."""
+    _lib, camera, ops = env
+    H, K = 16, 16
+    P1, P2 = _full_inputs(1, 4, H, 256, H * 4, seed=37)[:2]
+    g = torch.Generator().manual_seed(5)
+    ref = torch.randn(4, H, H, 256, generator=g).relu().cuda()
+    src = torch.randn(4, H, H, 256, generator=g).relu().cuda()
+    go = torch.randn(4, H, H, 256, generator=g).cuda()
+    src[1, 5, 6, 100] = 4e4                                  # pixel 86: not a multiple of four, i.e. outside the sample
+    src[2, 9, 3, 7] = -6e4
+    cam = camera.pair_algebra(P1, P2).cuda()
+    spec = ops.LayerSpec(H=H, W=H, K=K)
+    attn = ops.forward_nhwc(ops.LayerSpec(H=H, W=H, K=K, variant=_lib.ET_VARIANT_NO_TILE), ref, src, cam)[1]
+    gr_g, gs_g = ops.backward_nhwc(spec, ref, src, cam, go, form="gather")
+    for kw in (dict(), dict(attn=attn)):
+        gr_t, gs_t = ops.backward_nhwc(spec, ref, src, cam, go, form="tile", **kw)
+        for got, want in ((gr_t, gr_g), (gs_t, gs_g)):
+            assert torch.isfinite(got).all()
+            assert ((got - want).abs() - 1e-5 * want.abs()).max().item() <= TOL_GRAD_REL * max(want.abs().median().item() * 50, 1e-6)
+
+
 # ---------------------------------------------------------------------------------------
 # exported surface that had no test: et_residual_epilogue, the un-parameterised layer, MERGE early / both
 # ---------------------------------------------------------------------------------------
