@@ -389,11 +389,13 @@ def mpjpe_delta(dev):
 
 def cpu_baseline(args, spec, feat_ref, feat_src, P_ref, P_src):
     """The reference CPU path on this box's host cores, on a bounded sample of the same workload:
-      * kind "reference-op-sequence": oracle/torch_ref_path.py -- the ops the reference executes per pair
+      * `cpu_baseline` (kind "port", `implementation` "reference-op-sequence"): oracle/torch_ref_path.py -- the ops the
+        reference executes per pair
         (grid_sample twice on the stride-0 expanded map, broadcast mul + sum, mask, soft-max, weighted sum;
         epipolar.py:188-247), PyTorch CPU with every core.  /root/reference itself does not exist on the GPU box;
         the file is checked against outputs of the real reference in tests/test_oracle_golden.py.
-      * "port": oracle/epipolar_oracle.c, the scalar C restatement with OpenMP over pixels (beside it)."""
+      * `cpu_baseline_port` (kind "port", `implementation` "c-openmp"): oracle/epipolar_oracle.c, the scalar C
+        restatement with OpenMP over pixels (beside it)."""
     from oracle import oracle as orc
     from oracle import torch_ref_path as trp
 
@@ -407,7 +409,10 @@ def cpu_baseline(args, spec, feat_ref, feat_src, P_ref, P_src):
     locs = orc.sample_locs(ospec, P_ref[:n_t], P_src[:n_t])
     trp.forward_timed(f1[:1], f2[:1], locs[:, :1], cores)                       # warm-up (first call ~2.5x slower)
     dt_t, _ = trp.forward_timed(f1, f2, locs, cores)
-    ref = {"value": n_t / dt_t, "unit": "pair-views/s", "cores": cores, "kind": "reference-op-sequence",
+    # kind: the contract knows "reference" (the reference's own binary: there is none to ship -- upstream is Python and
+    # does not exist on the GPU box) and "port"; this is a port that keeps the reference's op sequence
+    ref = {"value": n_t / dt_t, "unit": "pair-views/s", "cores": cores, "kind": "port",
+           "implementation": "reference-op-sequence (oracle/torch_ref_path.py, PyTorch CPU)",
            "sample": "%d of the %d pairs of one GPU's batch, fused sample+attention only (no z/BN), the reference's "
                      "per-pair op sequence (oracle/torch_ref_path.py) in PyTorch CPU with %d threads, %.2f s of wall time"
                      % (n_t, feat_ref.shape[0], cores, dt_t)}
@@ -422,6 +427,7 @@ def cpu_baseline(args, spec, feat_ref, feat_src, P_ref, P_src):
         orc.forward_fused_timed(ospec, f1, f2, P_ref[:n], P_src[:n])
     dt = time.perf_counter() - t0
     port = {"value": n * args.cpu_reps / dt, "unit": "pair-views/s", "cores": threads, "kind": "port",
+            "implementation": "c-openmp (oracle/epipolar_oracle.c)",
             "sample": "%d x %d of the %d pairs of one GPU's batch, fused sample+attention only (no z/BN), "
                       "oracle/epipolar_oracle.c with OpenMP on %d threads, %.2f s of CPU wall time"
                       % (args.cpu_reps, n, feat_ref.shape[0], threads, dt)}

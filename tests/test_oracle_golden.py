@@ -81,7 +81,7 @@ def test_backward_matches_reference_autograd(oracle_mod, case):
 
 @pytest.mark.parametrize("case", golden_cases())
 def test_torch_op_sequence_vs_reference(case):
-    """oracle/torch_ref_path.py (the reference's executed op sequence, used as bench.py's "reference-op-sequence"
+    """oracle/torch_ref_path.py (the reference's executed op sequence, used as bench.py's `cpu_baseline`, implementation "reference-op-sequence"
     CPU baseline) reproduces the real reference's outputs on the fixtures."""
     import torch
 
