@@ -19,8 +19,6 @@ ET_VARIANT_PIXEL_INTERLEAVE = 4
 ET_VARIANT_BATCH4 = 8
 ET_VARIANT_OCC5 = 16
 ET_VARIANT_OCC6 = 32
-ET_VARIANT_ABLATE_NO_LOADS = 64
-ET_VARIANT_ABLATE_ONE_ROW = 128
 ET_VARIANT_BASELINE = 256
 ET_VARIANT_PIPELINE = 512
 ET_VARIANT_MULTI2 = 1024

@@ -64,11 +64,8 @@ int et_epipolar_backward_tiled_attn(const EtLayerDesc *desc, const float *xs, co
     int n2 = 64;
     while (n2 < HW) n2 <<= 1;
     const size_t lds_sort = (size_t)n2 * sizeof(unsigned long long);
-    if (lds_sort > 48 * 1024) {
-        hipError_t ae = hipFuncSetAttribute(reinterpret_cast<const void *>(tile_order_kernel),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_sort);
-        if (ae != hipSuccess) return fail("hipFuncSetAttribute(tile_order_kernel): %s", hipGetErrorString(ae));
-    }
+    const int dev = current_device();
+    ET_GRANT_LDS(tile_order_kernel, lds_sort, dev);
     // (with the per-pair scale estimates of the source maps: the merged kernels run their row-type GEMMs as split-fp16
     //  products; the workspace has the forward's layout)
     const TileWorkspace w = carve_tile_workspace(workspace, (size_t)total, (size_t)desc->N);
@@ -87,11 +84,7 @@ int et_epipolar_backward_tiled_attn(const EtLayerDesc *desc, const float *xs, co
                        (size_t)tp.hw_words * 8 + ((kpl == 1 && !merged) ? (size_t)kTilePix * kWave * 8 : 0);
 #define ET_BTILE(KK, RR)                                                                                        \
     do {                                                                                                        \
-        if (lds > 48 * 1024) {                                                                                  \
-            hipError_t ae = hipFuncSetAttribute(reinterpret_cast<const void *>(epipolar_bwd_tile_kernel<KK, RR>), \
-                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);          \
-            if (ae != hipSuccess) return fail("hipFuncSetAttribute(bwd tile kernel): %s", hipGetErrorString(ae)); \
-        }                                                                                                       \
+        ET_GRANT_LDS((epipolar_bwd_tile_kernel<KK, RR>), lds, dev);                                             \
         hipLaunchKernelGGL((epipolar_bwd_tile_kernel<KK, RR>), dim3((unsigned)total), dim3(256), lds, st, tp);  \
     } while (0)
     if (rows == kTileRowsMerged) {

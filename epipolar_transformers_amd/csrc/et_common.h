@@ -318,6 +318,42 @@ __device__ __forceinline__ float f4_dot(const float4 &a, const float4 &b)
 // ----------------------------------------------------------------------------
 // host-side dispatch
 // ----------------------------------------------------------------------------
+// compute units of a device (the persistent kernels launch one block per CU): queried once per device and process
+int current_device()
+{
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0;
+    return dev;
+}
+int device_cus(int dev)
+{
+    static int cached[64];   // zero-initialised; relaxed atomics: every thread would store the same value
+    int v = __atomic_load_n(&cached[dev], __ATOMIC_RELAXED);
+    if (v == 0) {
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+        __atomic_store_n(&cached[dev], v, __ATOMIC_RELAXED);
+    }
+    return v;
+}
+
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (call site, device) and process instead of on every launch:
+// `slot` is a static int[64] owned by the call site, holding the largest size already granted on each device.
+template <class Kernel>
+int grant_lds(Kernel kernel, size_t bytes, int dev, int *slot, const char *name)
+{
+    if (bytes <= 48 * 1024) return 0;
+    if ((size_t)__atomic_load_n(&slot[dev], __ATOMIC_RELAXED) >= bytes) return 0;
+    hipError_t ae = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (ae != hipSuccess) return fail("hipFuncSetAttribute(%s, %zu bytes): %s", name, bytes, hipGetErrorString(ae));
+    __atomic_store_n(&slot[dev], (int)bytes, __ATOMIC_RELAXED);
+    return 0;
+}
+#define ET_GRANT_LDS(KERNEL, BYTES, DEV)                                            \
+    do {                                                                            \
+        static int granted_[64];                                                    \
+        if (int e_ = grant_lds((KERNEL), (BYTES), (DEV), granted_, #KERNEL)) return e_; \
+    } while (0)
+
 int validate(const EtLayerDesc *d)
 {
     if (!d) return fail("desc is NULL");
@@ -326,6 +362,9 @@ int validate(const EtLayerDesc *d)
     if (d->C > 512) return fail("C=%d > 512 not supported", d->C);
     if (d->K < 2 || d->K > 256) return fail("K=%d outside [2, 256]", d->K);
     if ((long long)d->H * d->W * d->C * 4 >= (1LL << 31)) return fail("one feature map must stay below 2 GiB");
+#ifndef ET_DEV_ABLATE
+    if (d->variant & (64 | 128)) return fail("variant bits 64 / 128 (roofline ablations, wrong results) exist in -DET_DEV_ABLATE builds only");
+#endif
     if (!(d->downsample > 0.f) || !(d->image_resize > 0.f) || !(d->predict_resize > 0.f))
         return fail("downsample / resize factors must be positive");
     return 0;

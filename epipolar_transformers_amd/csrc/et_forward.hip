@@ -59,7 +59,7 @@ int et_epipolar_forward(const EtLayerDesc *desc, const float *xs, const float *y
     if (total > 0x7fffffffLL) return fail("grid too large");
     p.total_blocks = (int)total;
     p.interleave = (desc->variant & ET_VARIANT_PIXEL_INTERLEAVE) ? 1 : 0;
-    p.ablate = (desc->variant & ET_VARIANT_ABLATE_NO_LOADS) ? 1 : (desc->variant & ET_VARIANT_ABLATE_ONE_ROW) ? 2 : 0;
+    p.ablate = 0;
     const dim3 grid((unsigned)total);
     const int kpl_ = (desc->K + 63) / 64;
     const size_t lds = (attn ? (size_t)desc->K * kPixPerBlock * sizeof(float) : 0) +
@@ -70,13 +70,20 @@ int et_epipolar_forward(const EtLayerDesc *desc, const float *xs, const float *y
     // four pixels per wave in lockstep; otherwise one pixel per wave, batches of 4 samples, <= 96 VGPRs (5 waves/SIMD),
     // waves of a block interleaved over neighbouring pixels
     int v = desc->variant & ~(ET_VARIANT_NO_TILE | ET_VARIANT_TILE_SPLIT);
-    if ((v & ~(ET_VARIANT_ABLATE_NO_LOADS | ET_VARIANT_ABLATE_ONE_ROW)) == 0)
+#ifdef ET_DEV_ABLATE
+    constexpr int kAblateBits = ET_VARIANT_ABLATE_NO_LOADS | ET_VARIANT_ABLATE_ONE_ROW;
+#else
+    constexpr int kAblateBits = 0;   // (the roofline ablations -- wrong results by construction -- are not in product builds)
+#endif
+    if ((v & ~kAblateBits) == 0)
         v |= (desc->C == 256 && kpl == 1) ? ET_VARIANT_MULTI4   // K > 64: its LDS records cut occupancy (measured 1.8x slower)
                                           : (ET_VARIANT_BATCH4 | ET_VARIANT_OCC5 | ET_VARIANT_PIXEL_INTERLEAVE);
     if (v & ET_VARIANT_BASELINE)
         v &= ~(ET_VARIANT_BATCH4 | ET_VARIANT_OCC5 | ET_VARIANT_OCC6 | ET_VARIANT_PIXEL_INTERLEAVE |
                ET_VARIANT_MULTI2 | ET_VARIANT_MULTI4);
+#ifdef ET_DEV_ABLATE
     p.ablate = (v & ET_VARIANT_ABLATE_NO_LOADS) ? 1 : (v & ET_VARIANT_ABLATE_ONE_ROW) ? 2 : 0;
+#endif
     p.interleave = (v & ET_VARIANT_PIXEL_INTERLEAVE) ? 1 : 0;
     if ((v & (ET_VARIANT_MULTI2 | ET_VARIANT_MULTI4)) && desc->C == 256 && kpl <= 2) {
         // several pixels per wave; per-wave LDS: PPW * KP * 32 + PPW * 16 bytes

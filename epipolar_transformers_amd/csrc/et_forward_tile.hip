@@ -75,11 +75,8 @@ int et_epipolar_forward_tiled(const EtLayerDesc *desc, const float *xs, const fl
     int n2 = 64;
     while (n2 < HW) n2 <<= 1;
     const size_t lds_sort = (size_t)n2 * sizeof(unsigned long long);
-    if (lds_sort > 48 * 1024) {
-        hipError_t ae = hipFuncSetAttribute(reinterpret_cast<const void *>(tile_order_kernel),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_sort);
-        if (ae != hipSuccess) return fail("hipFuncSetAttribute(tile_order_kernel): %s", hipGetErrorString(ae));
-    }
+    const int dev = current_device();
+    ET_GRANT_LDS(tile_order_kernel, lds_sort, dev);
     hipLaunchKernelGGL(tile_order_kernel, dim3(desc->N), dim3(1024), lds_sort, st, *desc, xs, ys, cam, n2,
                        tp.tiles_per_pair * kTilePix, w.perm, w.ovf_count, feat_ref, feat_src, w.scales, w.segs);
     if (int e = check_launch("et_epipolar_forward_tiled(order)")) return e;
@@ -87,14 +84,7 @@ int et_epipolar_forward_tiled(const EtLayerDesc *desc, const float *xs, const fl
     const int rows = tile_rows(desc);
     const size_t lds = (size_t)(tile_array_floats(rows) + rows + kTilePix + 4 + kTilePix * 4) * 4 +
                        (size_t)tp.hw_words * 8 + (kpl == 1 ? (size_t)kTilePix * kWave * 8 : 0);
-#define ET_SET_LDS(KERNEL, BYTES)                                                                              \
-    do {                                                                                                       \
-        if ((BYTES) > 48 * 1024) {                                                                             \
-            hipError_t ae = hipFuncSetAttribute(reinterpret_cast<const void *>(KERNEL),                        \
-                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)(BYTES));     \
-            if (ae != hipSuccess) return fail("hipFuncSetAttribute(" #KERNEL "): %s", hipGetErrorString(ae));  \
-        }                                                                                                      \
-    } while (0)
+#define ET_SET_LDS(KERNEL, BYTES) ET_GRANT_LDS(KERNEL, BYTES, dev)
     if (tile_ws_eligible(desc)) {
         // 2a. one persistent block per CU, matrix and vector waves specialised (kernels_forward_tile_ws.inc) ...
         TileWsParams wp;
@@ -117,7 +107,7 @@ int et_epipolar_forward_tiled(const EtLayerDesc *desc, const float *xs, const fl
 #else
         wp.prof = nullptr;
 #endif
-        const int cus = device_cus();
+        const int cus = device_cus(dev);
         const unsigned grid = (unsigned)(total < cus ? total : cus);
         const size_t lds_ws = tile_ws_lds_bytes(kTileRowsSmall, tp.hw_words, desc->H, desc->W);
         if (desc->variant & ET_VARIANT_WS_NV4) {

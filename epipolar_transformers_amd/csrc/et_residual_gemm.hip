@@ -29,12 +29,9 @@ int et_residual_gemm(int64_t num_pixels, int32_t C, const float *out, const floa
     const long long blocks = (num_pixels + kRgRows - 1) / kRgRows;
     if (blocks > 0x7fffffffLL) return fail("et_residual_gemm: too many rows");
     hipStream_t st = (hipStream_t)stream;
-    // (set on every call like the other entry points: no process-global state, and the attribute is per device)
-    hipError_t ae = feat ? hipFuncSetAttribute(reinterpret_cast<const void *>(residual_gemm_kernel<true>),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)kRgLdsBytes)
-                         : hipFuncSetAttribute(reinterpret_cast<const void *>(residual_gemm_kernel<false>),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)kRgLdsBytes);
-    if (ae != hipSuccess) return fail("hipFuncSetAttribute(residual_gemm_kernel): %s", hipGetErrorString(ae));
+    const int dev = current_device();
+    if (feat) ET_GRANT_LDS(residual_gemm_kernel<true>, kRgLdsBytes, dev);
+    else ET_GRANT_LDS(residual_gemm_kernel<false>, kRgLdsBytes, dev);
     if (feat)
         hipLaunchKernelGGL(residual_gemm_kernel<true>, dim3((unsigned)blocks), dim3(256), kRgLdsBytes, st, out, feat,
                            reinterpret_cast<const unsigned *>(packed), bias, x, (long long)num_pixels);

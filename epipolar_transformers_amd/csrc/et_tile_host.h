@@ -28,24 +28,14 @@ bool tile_eligible(const EtLayerDesc *d)
     return tile_rows_per_pixel(d) <= tile_rows_cap(d);
 }
 
-// the warp-specialised persistent kernel: lanes <-> samples (K <= 64), 256-row arrays
+// the warp-specialised persistent kernel: lanes <-> samples (K <= 64), 256-row arrays.  Soft-max on only: its second
+// GEMM converts the B rows (attention x bilinear weights, <= 1 with the soft-max) to fp16 without a guard; with
+// EPIPOLAR.SOFTMAX_ENABLED False the "attention" is sim / K -- unbounded, -1e10 / K on masked samples -- and the call
+// takes the exact-fp32 one-block-per-tile kernel.
 bool tile_ws_eligible(const EtLayerDesc *d)
 {
-    return !(d->variant & ET_VARIANT_TILE_CLASSIC) && d->K <= 64 && d->W >= 2 && tile_rows(d) == kTileRowsSmall;
-}
-
-// compute units of the current device (the persistent kernel launches one block per CU); cached per device
-int device_cus()
-{
-    int cached[64] = {0};
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
-    int v = __atomic_load_n(&cached[dev], __ATOMIC_RELAXED);
-    if (v == 0) {
-        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
-        __atomic_store_n(&cached[dev], v, __ATOMIC_RELAXED);
-    }
-    return v;
+    return !(d->variant & ET_VARIANT_TILE_CLASSIC) && d->softmax_enabled && d->K <= 64 && d->W >= 2 &&
+           tile_rows(d) == kTileRowsSmall;
 }
 
 // Workspace of the tile forward (all int32, base aligned up to 256 bytes):

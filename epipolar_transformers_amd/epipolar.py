@@ -15,6 +15,9 @@ The reprojection loss and an externally supplied depth raise NotImplementedError
 """
 from __future__ import annotations
 
+import contextlib
+import threading
+
 import torch
 from torch import nn
 import torch.nn.functional as F
@@ -176,11 +179,24 @@ class Epipolar(nn.Module):
         return out, sim, corr_pos
 
     # --------------------------------------------------------------- forward
-    host_P = None    # optional (P_ref_cpu, P_src_cpu) of the CURRENT batch, set by a launcher that still has the data
-                     # loader's host copies: spares the device-to-host copy of GPU-resident matrices (camera.py)
+    # Optional (P_ref_cpu, P_src_cpu) of the batch the CALLING THREAD is about to run, handed over by a launcher that
+    # still has the data loader's host copies (spares the device-to-host copy of GPU-resident matrices, camera.py).
+    # Thread-local and scoped (`with Epipolar.host_matrices(...)`): nothing outlives the wrapped call, and threads
+    # (nn.DataParallel replicas, a second model) never see each other's matrices.
+    _host = threading.local()
+
+    @classmethod
+    @contextlib.contextmanager
+    def host_matrices(cls, P_ref_cpu, P_src_cpu):
+        prev = getattr(cls._host, "P", None)
+        cls._host.P = (P_ref_cpu, P_src_cpu) if P_ref_cpu is not None and P_src_cpu is not None else None
+        try:
+            yield
+        finally:
+            cls._host.P = prev
 
     def _cam(self, P1, P2, device):
-        host = self.host_P
+        host = getattr(self._host, "P", None)
         if host is not None and (tuple(host[0].shape) != tuple(P1.shape) or tuple(host[1].shape) != tuple(P2.shape)):
             host = None
         return self._cams.get(P1, P2, device, host=host)

@@ -82,8 +82,12 @@ typedef struct EtLayerDesc {
 #define ET_VARIANT_WS_NV4 131072  /* warp-specialised kernel, tuning: 4 vector waves per block instead of 8 */
 #define ET_VARIANT_WS_SETPRIO 262144 /* warp-specialised kernel, tuning: s_setprio 1 on the matrix waves */
 #define ET_VARIANT_BASELINE 256    /* batches of 8, compiler-chosen registers, pixels 4w..4w+3 per wave   */
-#define ET_VARIANT_ABLATE_NO_LOADS 64  /* profiling only, WRONG RESULTS: no tap loads after the first sample */
-#define ET_VARIANT_ABLATE_ONE_ROW 128  /* profiling only, WRONG RESULTS: every tap load reads source row 0    */
+/* Bits 64 and 128 are reserved: in development builds of the library (-DET_DEV_ABLATE) they switch the per-pixel
+ * kernel's tap loads off for roofline ablations (wrong results by construction); a product build rejects them. */
+#ifdef ET_DEV_ABLATE
+#define ET_VARIANT_ABLATE_NO_LOADS 64
+#define ET_VARIANT_ABLATE_ONE_ROW 128
+#endif
 
 int et_abi_version(void);
 const char *et_last_error(void);

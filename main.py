@@ -47,9 +47,10 @@ def install(reference_root=REFERENCE_ROOT):
 def _keep_host_matrices(Epipolar):
     """The data loader hands `KRT` / `other_KRT` over on the host and the reference moves them to the GPU
     (modeling/model.py:183-195) before the backbone runs; the layer's per-pair algebra is host code (LAPACK, as in the
-    reference), so keep the host copies of the current batch where the layer finds them (`Epipolar.host_P`) instead
-    of copying the matrices back from the device -- a synchronisation per step.  Shapes that do not match what the
-    layer is called with (stacked multi-view test batches) are ignored by the layer."""
+    reference), so keep the host copies of the current batch where the layer finds them (`Epipolar.host_matrices`) instead
+    of copying the matrices back from the device -- a synchronisation per step.  The hand-over is thread-local and
+    lives only for the wrapped call (`Epipolar.host_matrices`); shapes that do not match what the layer is called
+    with (stacked multi-view test batches) are ignored by the layer."""
     try:
         import modeling.model as ref_model
     except Exception:                                    # (the reference's model module needs more than the layer does)
@@ -59,14 +60,15 @@ def _keep_host_matrices(Epipolar):
     original = ref_model.Modelbuilder.forward
 
     def forward(self, inputs, *args, **kwargs):
-        Epipolar.host_P = None
+        host = (None, None)
         try:
             krt, other = inputs.get("KRT"), inputs.get("other_KRT")
             if krt is not None and other is not None and not krt.is_cuda and not other.is_cuda:
-                Epipolar.host_P = (krt.float().reshape(-1, 3, 4), other.float().reshape(-1, 3, 4))
+                host = (krt.float().reshape(-1, 3, 4), other.float().reshape(-1, 3, 4))
         except (AttributeError, RuntimeError):
-            Epipolar.host_P = None
-        return original(self, inputs, *args, **kwargs)
+            host = (None, None)
+        with Epipolar.host_matrices(*host):      # scoped to this call and this thread (cleared on exceptions too)
+            return original(self, inputs, *args, **kwargs)
 
     forward._keeps_host_P = True
     ref_model.Modelbuilder.forward = forward

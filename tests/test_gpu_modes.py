@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import GOLDEN_DIR
+from conftest import GOLDEN_DIR, assert_corr_pos
 
 pytestmark = pytest.mark.gpu
 
@@ -53,25 +53,44 @@ def test_mode_vs_reference(name):
         kw.update(ref1=dev("rgb1"), ref2=dev("rgb2"))
     fin, corr, depth, _ = mod(f1, f2, torch.from_numpy(d["P1"]), torch.from_numpy(d["P2"]), **kw)
     assert tuple(fin.shape) == d["finalout"].shape and tuple(depth.shape) == d["depth"].shape
+    from epipolar_transformers_amd import ops
+
+    # corr_pos may differ from the reference's only where the arg-max has a PROVEN tie in our own similarity (`depth`)
+    locs = ops.sample_locs(mod.layer_spec(), torch.from_numpy(d["cam"]).cuda()).cpu().numpy()      # (K,N,H,W,2)
+    got_corr, depth_np = corr.cpu().numpy(), depth.detach().cpu().numpy()
+    ties = assert_corr_pos(locs, got_corr, d["corr_pos"], depth_np, True, tie=2e-6, max_frac=2e-2)   # (N,H,W) bool
+    assert np.abs(depth_np - d["depth"]).max() <= 1e-5 * max(1.0, float(np.abs(d["depth"]).max()))
     scale = max(1.0, float(np.abs(d["finalout"]).max()))
     err = np.abs(fin.detach().cpu().numpy() - d["finalout"])
-    if "attention_max" in name:
-        # ATTENTION max gathers the arg-max sample: a near-tie between two samples resolves differently under GPU
-        # rounding and flips that pixel's whole output vector -- everything else must agree
-        assert (err.max(1) <= 1e-4 * scale).mean() >= 0.99
+    is_max = "attention_max" in name
+    if is_max:
+        # ATTENTION max GATHERS the arg-max sample: at a proven tie the other (equally good) sample's features come
+        # out -- those pixels, and only those, are exempt; every other pixel must agree
+        assert (err.max(1) <= 1e-4 * scale)[~ties].all()
     else:
         assert err.max() <= 1e-4 * scale
-    assert np.abs(depth.detach().cpu().numpy() - d["depth"]).max() <= 1e-5 * max(1.0, float(np.abs(d["depth"]).max()))
-    neq = (corr.cpu().numpy() != d["corr_pos"]).any(-1)
-    assert neq.mean() <= 2e-2                                  # arg-max ties (checked strictly on the fused path)
     (fin * dev("grad_out")).sum().backward()
-    for got, want in ((f1.grad, d["grad_feat1"]), (f2.grad, d["grad_feat2"])):
+    # gradient entries a tie pixel touches (ATTENTION max only): its own d(feat1) vector and d(feat2) at the taps of
+    # the two tied samples
+    N, _, H, W = d["feat1"].shape
+    touched2 = np.zeros((N, H, W), dtype=bool)
+    if is_max and ties.any():
+        for pos in (got_corr, d["corr_pos"]):                                   # de-normalised (x, y), multiview.py:50-57
+            for n, h, w in zip(*np.nonzero(ties)):
+                gx = ((pos[n, h, w, 0] * 2.0 / (W - 1)) * W - 1) / 2           # tap space of grid_sample (align_corners=False)
+                gy = ((pos[n, h, w, 1] * 2.0 / (H - 1)) * H - 1) / 2
+                for yy in (int(np.floor(gy)) - 1, int(np.floor(gy)), int(np.floor(gy)) + 1, int(np.floor(gy)) + 2):
+                    for xx in (int(np.floor(gx)) - 1, int(np.floor(gx)), int(np.floor(gx)) + 1, int(np.floor(gx)) + 2):
+                        if 0 <= yy < H and 0 <= xx < W:
+                            touched2[n, yy, xx] = True                          # (one pixel of slack around the 2x2 taps)
+    for got, want, exempt in ((f1.grad, d["grad_feat1"], ties if is_max else None),
+                              (f2.grad, d["grad_feat2"], touched2 if is_max else None)):
         got = np.zeros_like(want) if got is None else got.cpu().numpy()
-        gerr = np.abs(got - want)
-        if "attention_max" in name:
-            assert (gerr <= 1e-4 * max(float(np.abs(want).max()), 1e-6)).mean() >= 0.97
-        else:
-            assert gerr.max() <= 1e-4 * max(float(np.abs(want).max()), 1e-6)
+        gerr = np.abs(got - want).max(1)                                        # (N,H,W)
+        ok = gerr <= 1e-4 * max(float(np.abs(want).max()), 1e-6)
+        assert ok.all() if exempt is None else ok[~exempt].all()
+        if exempt is not None:
+            assert exempt.mean() <= 0.1
 
 
 def test_param_yaml_runs_through_the_backbone():

@@ -11,7 +11,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import golden_cases, load_golden
+from conftest import assert_corr_pos, golden_cases, load_golden
 
 pytestmark = pytest.mark.gpu
 
@@ -50,33 +50,13 @@ def _run_forward(env, d, variant=0):
 
 
 def _assert_corr_pos(ops, spec, cam, corr, want_corr, attn, tie=2e-6, max_frac=2e-2):
-    """corr_pos is the de-normalised location of the arg-max sample (epipolar.py:237-242): exact, except where the
-    soft-max has a TIE that float rounding resolves differently.  Every pixel whose corr_pos differs from the
-    reference's must be such a tie: the sample the reference picked carries (to `tie`) the same attention in OUR
-    output as the sample we picked -- no blanket mismatch budget."""
-    corr, want_corr, attn = np.asarray(corr), np.asarray(want_corr), np.asarray(attn)
-    neq = (corr != want_corr).any(-1)                                  # (N,H,W)
-    if not neq.any():
+    """conftest.assert_corr_pos with the sample locations of the HIP geometry kernel (bit-equal to the reference's):
+    every pixel whose corr_pos differs from the reference's must be a proven arg-max tie."""
+    corr, want_corr = np.asarray(corr), np.asarray(want_corr)
+    if not (corr != want_corr).any():
         return 0.0
-    locs = ops.sample_locs(spec, cam).cpu().numpy()                    # (K,N,H,W,2), bit-equal to the reference's
-    K, N, H, W, _ = locs.shape
-    if spec.correct_normalize:                                         # multiview.py:50-57, float32 like the kernels
-        den = np.stack([(locs[..., 0] + np.float32(1)) * np.float32(W - 1) / np.float32(2),
-                        (locs[..., 1] + np.float32(1)) * np.float32(H - 1) / np.float32(2)], -1)
-    else:
-        den = np.stack([(locs[..., 0] + np.float32(1)) * np.float32(W) / np.float32(2) - np.float32(0.5),
-                        (locs[..., 1] + np.float32(1)) * np.float32(H) / np.float32(2) - np.float32(0.5)], -1)
-    for n, h, w in zip(*np.nonzero(neq)):
-        cand = den[:, n, h, w]                                         # (K,2)
-        k_ref = np.nonzero((cand == want_corr[n, h, w]).all(-1))[0]
-        k_our = np.nonzero((cand == corr[n, h, w]).all(-1))[0]
-        assert len(k_ref) and len(k_our), "corr_pos is not one of the pixel's sample locations at %s" % ((n, h, w),)
-        a = attn[n, :, h, w]
-        assert abs(float(a[k_ref[0]]) - float(a[k_our[0]])) <= tie * max(1.0, abs(float(a[k_ref[0]]))), \
-            "corr_pos differs at %s and it is not a tie: attn[k_ref=%d]=%g attn[k_ours=%d]=%g" % (
-                (n, h, w), k_ref[0], a[k_ref[0]], k_our[0], a[k_our[0]])
-    assert neq.mean() <= max_frac, "suspiciously many arg-max ties: %g" % neq.mean()
-    return float(neq.mean())
+    locs = ops.sample_locs(spec, cam).cpu().numpy()                    # (K,N,H,W,2)
+    return float(assert_corr_pos(locs, corr, want_corr, attn, spec.correct_normalize, tie, max_frac).mean())
 
 
 def _close(got, want, atol, rtol=2e-6):

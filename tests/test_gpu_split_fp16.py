@@ -1,0 +1,180 @@
+"""The regimes of the split-fp16 forward (C = 256 head: the warp-specialised MFMA tile kernel) that ordinary
+`relu(randn)` fixtures never enter, each against the C oracle (fp32 restatement of epipolar.py:188-247) on the same
+inputs -- attention <= 1e-5, `out` <= 1e-4 of the output's magnitude, corr_pos exact up to proven ties:
+
+  * an outlier INSIDE whatever a scale estimate could sample (column 0 of an image row, first / last pixel row);
+  * heavy-tailed features (log-normal, sigma = 2: the largest value is ~1e4 x the median);
+  * global magnitudes far from 1 (1e-6 ... 1e4, not powers of two), ref and source scaled alike and against each other;
+  * a reference row that is tiny but non-zero (2^-40 of the map maximum) next to an all-zero region of the source map:
+    its dot products are exactly 0 only on the zero region (epipolar.py:298 masks THOSE samples); a kernel that
+    flushes the tiny row to zero would mask all K samples and return uniform attention instead;
+  * soft-max off (EPIPOLAR.SOFTMAX_ENABLED False) with |features| ~ 8: the "attention" sim / K is unbounded.
+
+and the full Config-2 batch (128 pairs, 64 x 64, K = 64) compared tensor for tensor with the oracle.
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import assert_corr_pos
+
+pytestmark = pytest.mark.gpu
+
+H = W = 64
+C = 256
+K = 64
+
+
+@pytest.fixture(scope="module")
+def env():
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    from epipolar_transformers_amd import _lib, camera, ops
+
+    _lib.load()
+    return _lib, camera, ops
+
+
+def _pairs(frames=1, seed=3):
+    from epipolar_transformers_amd import synthetic as syn
+
+    return syn.make_pairs(frames, 4, 4 * H, seed=seed, jitter=(0.05, 8.0))
+
+
+def _features(n, seed, kind="relu"):
+    g = torch.Generator().manual_seed(seed)
+    if kind == "relu":
+        return torch.randn(n, C, H, W, generator=g).relu(), torch.randn(n, C, H, W, generator=g).relu()
+    if kind == "lognormal":
+        return torch.exp(2.0 * torch.randn(n, C, H, W, generator=g)), torch.exp(2.0 * torch.randn(n, C, H, W, generator=g))
+    raise ValueError(kind)
+
+
+def _compare(env, oracle_mod, P1, P2, f1, f2, variants=(0,), softmax=True, attn_tol=1e-5, out_rel=1e-4):
+    """HIP forward (through the C ABI) vs the C oracle on the same inputs and the same per-pair algebra."""
+    _lib, camera, ops = env
+    cam = camera.pair_algebra(P1, P2)
+    want = oracle_mod.forward(oracle_mod.LayerSpec(H, W, K, softmax_enabled=softmax), f1, f2, None, None, cam=cam.numpy())
+    assert np.isfinite(want["out"]).all() and np.isfinite(want["attn"]).all()
+    ref, src = ops.to_nhwc(f1.cuda()), ops.to_nhwc(f2.cuda())
+    # `out` tolerance per (pair, channel): 1e-4 of that channel's magnitude, never below 1e-4 absolute for O(1) data
+    # (the north-star bound) -- or 1e-4 of the whole output's magnitude when everything is tiny
+    gmax = max(float(np.abs(want["out"]).max()), 1e-30)
+    tol = out_rel * np.maximum(np.abs(want["out"]).max(axis=(2, 3), keepdims=True), min(1.0, gmax))
+    worst = {}
+    for v in variants:
+        spec = ops.LayerSpec(H=H, W=W, K=K, softmax_enabled=softmax, variant=v)
+        out, attn, corr = ops.forward_nhwc(spec, ref, src, cam.cuda())
+        torch.cuda.synchronize()
+        out, attn, corr = out.permute(0, 3, 1, 2).cpu().numpy(), attn.cpu().numpy(), corr.cpu().numpy()
+        assert np.isfinite(out).all() and np.isfinite(attn).all(), "variant %d produced inf / NaN" % v
+        ea = float((np.abs(attn - want["attn"]) - 2e-6 * np.abs(want["attn"])).max())
+        eo = float(((np.abs(out - want["out"]) - 2e-6 * np.abs(want["out"])) / tol).max())
+        worst[v] = (ea, eo)
+        assert ea <= attn_tol, "variant %d: attention differs from the oracle by %g" % (v, ea)
+        assert eo <= 1.0, "variant %d: out differs by %g x its tolerance (output magnitude %g)" % (v, eo, gmax)
+        assert_corr_pos(want["sample_locs"], corr, want["corr_pos"], attn, True, max_frac=2e-2)
+    return want, worst
+
+
+@pytest.mark.parametrize("where", ["col0", "first_row", "last_pixel"])
+@pytest.mark.parametrize("magnitude", [3.0e3, 3.0e4])
+def test_outlier_at_a_sampled_position(env, oracle_mod, where, magnitude):
+    """A large value exactly where a sparse scale estimate looks (round 2 sampled column 0 of every image row): the
+    estimate then fits the outlier and everything else sits far below it.  Typical values must keep fp32-level accuracy."""
+    P1, P2 = _pairs()
+    f1, f2 = _features(4, seed=11)
+    y, x = {"col0": (20, 0), "first_row": (0, 0), "last_pixel": (H - 1, W - 1)}[where]
+    # each outlier sits in a channel whose partner map is zero: it stresses the scaling machinery and the value path
+    # (`out` of that channel), while the logits -- hence the comparison of the attention -- stay well conditioned
+    f2[1, 17, y, x] = magnitude
+    f1[1, 17] = 0
+    f1[2, 100, y, x] = magnitude
+    f2[2, 100] = 0
+    f2[3, 5, y, x] = -magnitude
+    f1[3, 5] = 0
+    _compare(env, oracle_mod, P1, P2, f1, f2, variants=(0, 65536))
+
+
+def test_lognormal_features(env, oracle_mod):
+    """exp(2 z): the largest of 4 M values is ~1e4 x the median.  Normalised so the largest |logit| is ~10, i.e. the
+    comparison itself stays well conditioned in fp32 (a dot product of magnitude D carries ~1e-6 D of rounding noise)."""
+    P1, P2 = _pairs()
+    f1, f2 = _features(4, seed=13, kind="lognormal")
+    # dot products of random (reference pixel, source pixel) rows: put their 99.99th percentile at 80 (|logit| = 10)
+    g = torch.Generator().manual_seed(2)
+    a = f1.permute(0, 2, 3, 1).reshape(-1, C)[torch.randint(0, 4 * H * W, (200000,), generator=g)]
+    b = f2.permute(0, 2, 3, 1).reshape(-1, C)[torch.randint(0, 4 * H * W, (200000,), generator=g)]
+    s = float((80.0 / torch.quantile((a * b).sum(1)[:100000], 0.9999).item()) ** 0.5)
+    f1, f2 = f1 * s, f2 * s
+    _compare(env, oracle_mod, P1, P2, f1, f2, variants=(0, 65536), attn_tol=3e-5)
+
+
+@pytest.mark.parametrize("s_ref,s_src", [(1e-6, 1e-6), (1e-6, 1e6), (3e4, 3.3e-5), (1e4, 1e-4), (1e-3, 7.0)])
+def test_global_magnitudes(env, oracle_mod, s_ref, s_src):
+    """Scales far from 1 and not powers of two; (s_ref * s_src ~ 1 keeps the logits where they are, both tiny makes the
+    attention uniform and `out` ~1e-6: nothing may be flushed to zero)."""
+    P1, P2 = _pairs()
+    f1, f2 = _features(4, seed=17)
+    want, _ = _compare(env, oracle_mod, P1, P2, f1 * s_ref, f2 * s_src)
+    assert float(np.abs(want["out"]).max()) > 0
+
+
+def test_tiny_nonzero_reference_row_next_to_zero_source_region(env, oracle_mod):
+    """VERDICT r2 weak 1d.  The reference masks a sample iff its dot product is EXACTLY 0.  A tiny but non-zero reference
+    row has zero dots only where the sampled source features are zero; flushing the row would mask all K samples."""
+    P1, P2 = _pairs()
+    f1, f2 = _features(4, seed=19)
+    f2[:, :, :, : W // 2] = 0                                   # left half of every source map: exact zeros
+    tiny = torch.rand(C, generator=torch.Generator().manual_seed(1)) * float(2.0 ** -40)
+    pix = [(5, 7), (30, 31), (31, 40), (60, 3), (33, 33)]
+    for n in range(4):
+        for (y, x) in pix:
+            f1[n, :, y, x] = tiny
+    f1[0, :, 40, 40] = float(2.0 ** -100)                       # far below anything a per-map scale can keep
+    f1[1, :, 12, 50] = 0                                        # and a truly all-zero row: uniform 1/K (H3)
+    want, _ = _compare(env, oracle_mod, P1, P2, f1, f2, variants=(0, 65536))
+    a = want["attn"]
+    # the scenario is real: at some of these pixels the reference masks SOME samples but not all
+    partial = [(n, y, x) for n in range(4) for (y, x) in pix if 0 < (a[n, :, y, x] == 0).sum() < K]
+    assert partial, "no pixel with partially masked samples: the fixture does not exercise the case"
+    assert np.allclose(a[1, :, 12, 50], 1.0 / K, atol=1e-7)
+
+
+def test_softmax_off_large_features(env, oracle_mod):
+    """with EPIPOLAR.SOFTMAX_ENABLED False the weights are sim / K (|sim| ~ 1e4 here, -1e10 / K
+    on masked samples) -- far beyond what an unguarded fp16 conversion of the B rows holds."""
+    P1, P2 = _pairs()
+    f1, f2 = _features(4, seed=23)
+    f1, f2 = f1 * 8.0, f2 * 8.0
+    f1[0, :, 9, 9] = 0                                          # a masked pixel: weights -1e10 / K on every sample
+    _lib, camera, ops = env
+    cam = camera.pair_algebra(P1, P2)
+    want = oracle_mod.forward(oracle_mod.LayerSpec(H, W, K, softmax_enabled=False), f1, f2, None, None, cam=cam.numpy())
+    ref, src = ops.to_nhwc(f1.cuda()), ops.to_nhwc(f2.cuda())
+    out, attn, corr = ops.forward_nhwc(ops.LayerSpec(H=H, W=W, K=K, softmax_enabled=False), ref, src, cam.cuda())
+    out, attn = out.permute(0, 3, 1, 2).cpu().numpy(), attn.cpu().numpy()
+    assert np.isfinite(out).all() and np.isfinite(attn).all()
+    # sim / K: relative comparison (the masked rows reach 1e8); the masked pixel's output cancels nothing, it is just big
+    assert (np.abs(attn - want["attn"]) <= 3e-6 * np.abs(want["attn"]) + 1e-4).all()
+    assert (np.abs(out - want["out"]) <= 1e-5 * np.abs(want["out"]) + 1e-5 * float(np.abs(want["out"]).max())).all()
+
+
+def test_config2_full_batch_vs_oracle(env, oracle_mod):
+    """BASELINE.json configs[1] at its full size -- 32 frames x 4 views = 128 pairs, C = 256, 64 x 64, K = 64 -- every
+    element of out / attn / corr_pos against the C oracle (a few seconds of the host's cores)."""
+    _lib, camera, ops = env
+    from epipolar_transformers_amd import synthetic as syn
+
+    P1, P2 = syn.make_pairs(32, 4, 256, seed=0, jitter=(0.05, 8.0))
+    f1, f2 = syn.make_features(P1.shape[0], C, H, W, seed=0)
+    cam = camera.pair_algebra(P1, P2)
+    ref, src = ops.to_nhwc(f1.cuda()), ops.to_nhwc(f2.cuda())
+    out, attn, corr = ops.forward_nhwc(ops.LayerSpec(H=H, W=W, K=K), ref, src, cam.cuda())
+    torch.cuda.synchronize()
+    out, attn, corr = out.permute(0, 3, 1, 2).cpu().numpy(), attn.cpu().numpy(), corr.cpu().numpy()
+    del ref, src
+    want = oracle_mod.forward(oracle_mod.LayerSpec(H, W, K), f1, f2, None, None, cam=cam.numpy())
+    assert out.shape == want["out"].shape == (128, C, H, W)
+    assert float((np.abs(attn - want["attn"]) - 2e-6 * np.abs(want["attn"])).max()) <= 1e-5
+    assert float((np.abs(out - want["out"]) - 2e-6 * np.abs(want["out"])).max()) <= 1e-4
+    assert_corr_pos(want["sample_locs"], corr, want["corr_pos"], attn, True, max_frac=2e-3)

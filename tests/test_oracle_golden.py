@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import golden_cases, load_golden
+from conftest import assert_corr_pos, golden_cases, load_golden
 
 
 def _spec(orc, d):
@@ -41,9 +41,8 @@ def test_forward_matches_reference(oracle_mod, case):
     # rows of attention sum to one when the softmax is on
     if d["dims"]["softmax"]:
         assert np.abs(r["attn"].sum(1) - 1.0).max() < 1e-5
-    # corr_pos is an argmax; ties between float-equal probabilities may flip
-    neq = (r["corr_pos"] != d["corr_pos"]).any(-1)
-    assert neq.mean() <= 2e-3, neq.mean()
+    # corr_pos is an arg-max: it may differ from the reference's only at PROVEN ties of the oracle's own attention
+    assert_corr_pos(r["sample_locs"], r["corr_pos"], d["corr_pos"], r["attn"], d["dims"]["correct"], max_frac=2e-3)
 
 
 @pytest.mark.parametrize("case", golden_cases())
@@ -97,4 +96,4 @@ def test_torch_op_sequence_vs_reference(case):
                                   correct_normalize=m["correct"])
     assert np.abs(out.numpy() - d["out"]).max() <= 5e-6 * max(1.0, float(np.abs(d["out"]).max()))
     assert np.abs(attn.numpy()[:, :, d["rows"]] - d["attn"]).max() <= 1e-6 * max(1.0, float(np.abs(d["attn"]).max()))
-    assert ((corr.numpy() != d["corr_pos"]).any(-1)).mean() <= 1e-3
+    assert_corr_pos(locs, corr.numpy(), d["corr_pos"], attn.numpy(), m["correct"], max_frac=1e-3)
