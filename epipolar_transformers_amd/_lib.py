@@ -10,7 +10,8 @@ import ctypes
 import os
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG, "lib", "libepipolar_amd.so")
+# EPIPOLAR_AMD_LIB: a development build of the same ABI (profiling counters, scripts/ws_profile.py); unset in production
+LIB_PATH = os.environ.get("EPIPOLAR_AMD_LIB") or os.path.join(_PKG, "lib", "libepipolar_amd.so")
 
 ET_CAM_STRIDE = 27
 ET_VARIANT_SAFE_REDUCE = 1

@@ -30,6 +30,9 @@ UNITS = {
 LIB = os.path.join(PKG, "lib", "libepipolar_amd.so")
 OBJ = os.path.join(PKG, "lib", "obj")
 ARCH = "gfx950"
+# development builds (never loaded by the product path): `--profile` adds the per-phase cycle counters of the
+# warp-specialised forward (scripts/ws_profile.py loads it through EPIPOLAR_AMD_LIB)
+PROFILE_LIB = os.path.join(PKG, "lib", "libepipolar_amd_prof.so")
 
 
 def _path(f):
@@ -43,13 +46,16 @@ def hipcc() -> str:
     raise RuntimeError("hipcc not found")
 
 
+_EXTRA = []      # extra defines of a development build (build_profile_library)
+
+
 def flags():
     return ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC",
-            "-I" + os.path.join(ROOT, "include"), "-I" + CSRC] + os.environ.get("ET_EXTRA_HIPCC_FLAGS", "").split()
+            "-I" + os.path.join(ROOT, "include"), "-I" + CSRC] + _EXTRA + os.environ.get("ET_EXTRA_HIPCC_FLAGS", "").split()
 
 
 def _obj(unit):
-    return os.path.join(OBJ, os.path.splitext(unit)[0] + ".o")
+    return os.path.join(OBJ + ("_dev" if _EXTRA else ""), os.path.splitext(unit)[0] + ".o")
 
 
 def _stale(unit) -> bool:
@@ -76,7 +82,7 @@ def build_library(force: bool = False, report: bool = False) -> str:
     """Compile the stale translation units in parallel (one hipcc per unit) and link them into LIB."""
     from concurrent.futures import ThreadPoolExecutor
 
-    os.makedirs(OBJ, exist_ok=True)
+    os.makedirs(os.path.dirname(_obj("x.hip")), exist_ok=True)
     todo = [u for u in UNITS if force or report or _stale(u)]
     logs = []
     if todo:
@@ -118,6 +124,23 @@ def resource_table(log: str) -> str:
     return "\n".join(out)
 
 
+def build_profile_library(defines=("-DET_WS_PROFILE=2",)) -> str:
+    """The same sources with development defines, linked into PROFILE_LIB (objects under lib/obj_dev)."""
+    global LIB
+    keep = LIB
+    _EXTRA[:] = list(defines)
+    LIB = PROFILE_LIB
+    try:
+        os.makedirs(OBJ + "_dev", exist_ok=True)
+        return build_library(force=True)
+    finally:
+        _EXTRA[:] = []
+        LIB = keep
+
+
 if __name__ == "__main__":
-    build_library(force=True, report="--report" in sys.argv)
-    print(LIB)
+    if "--profile" in sys.argv:
+        print(build_profile_library(tuple(a for a in sys.argv[1:] if a.startswith("-D")) or ("-DET_WS_PROFILE=2",)))
+    else:
+        build_library(force=True, report="--report" in sys.argv)
+        print(LIB)

@@ -27,14 +27,16 @@ def triangulate_dlt(points_2d: torch.Tensor, proj: torch.Tensor, conf: torch.Ten
     a0 = x[..., None] * row2 - P[:, :, None, 0, :]                    # (F,V,J,4)
     a1 = y[..., None] * row2 - P[:, :, None, 1, :]
     if conf is not None:
-        c = conf.to(torch.float64)
+        # triangulation.py:425-435: `conf > confthresh` compares the float32 scores with a Python float, i.e. IN FLOAT32
+        # (a score equal to float32(threshold) is not above it); the threshold itself steps down in float64
+        c = conf.to(torch.float32)
         thres = torch.full((F_, 1, J), conf_thres, dtype=torch.float64, device=pts.device)
-        for _ in range(64):                                           # triangulation.py:427-435
-            few = ((c > thres).sum(1, keepdim=True) <= 1) & (thres >= -1)
+        for _ in range(64):
+            few = ((c > thres.to(torch.float32)).sum(1, keepdim=True) <= 1) & (thres >= -1)
             if not bool(few.any()):
                 break
             thres = torch.where(few, thres - 0.05, thres)
-        keep = (c > thres).to(torch.float64)[..., None]               # (F,V,J,1)
+        keep = (c > thres.to(torch.float32)).to(torch.float64)[..., None]   # (F,V,J,1)
         a0, a1 = a0 * keep, a1 * keep                                 # a dropped view contributes zero rows
     A = torch.cat([a0, a1], 1).permute(0, 2, 1, 3)                    # (F,J,2V,4)
     _, _, vt = torch.linalg.svd(A, full_matrices=False)

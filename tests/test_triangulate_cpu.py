@@ -45,3 +45,28 @@ def test_mpjpe_scene_reference_detections_triangulate_near_ground_truth():
     X = triangulate_dlt(locs[None], P[None], torch.from_numpy(d["ref_scores"])[None])
     err = mpjpe(X[0], torch.from_numpy(d["joints"]))
     assert err.item() < 150.0                                # mm: 16x16 heat-maps, ~70 mm per image pixel
+
+
+def _triangulation_cases():
+    d = np.load(os.path.join(GOLDEN_DIR, "triangulation.npz"))
+    return d, sorted({k.split(".")[0] for k in d.files})
+
+
+def test_dlt_matches_the_reference_find3d_and_confidence_rule():
+    """Row N3 pinned to reference CODE: tests/golden/triangulation.npz holds what the reference's own
+    `triangulate_pymvg` -> `build_multi_camera_system` -> `MultiCameraSystem.find3d` (vision/triangulation.py:350-441,
+    vision/multi_camera_system.py:199-225) returned for these detections (tests/golden/make_triangulation_golden.py),
+    including joints whose threshold was lowered, views dropped at the float32 boundary and all-zero scores."""
+    d, names = _triangulation_cases()
+    assert len(names) >= 6
+    for name in names:
+        g = lambda k: d["%s.%s" % (name, k)]
+        P = torch.from_numpy(g("K")).double() @ torch.from_numpy(g("RT")).double()          # (V,3,4), as CameraModel.get_M
+        got = triangulate_dlt(torch.from_numpy(g("pts"))[None], P[None], torch.from_numpy(g("conf"))[None],
+                              conf_thres=float(g("thres")))[0].numpy()
+        want = g("X_ref")
+        err = np.linalg.norm(got - want, axis=1)
+        # the reference camera keeps R as a quaternion: its M differs from K @ RT by ~2e-8 relative (float32 R is not
+        # exactly orthonormal), i.e. ~1e-4 mm at 5 m; joints whose selected views nearly agree are worse conditioned
+        scale = np.maximum(1.0, np.linalg.norm(want - g("X_true"), axis=1))
+        assert (err <= 2e-3 * scale).all(), (name, float(err.max()), int(err.argmax()))
