@@ -29,9 +29,9 @@ ET_VARIANT_BWD_UNSORTED = 8192
 ET_VARIANT_NO_TILE = 16384
 ET_VARIANT_TILE_SPLIT = 32768
 ET_VARIANT_TILE_CLASSIC = 65536
-ET_VARIANT_WS_NV4 = 131072
+ET_VARIANT_WS_V1 = 131072
 ET_VARIANT_WS_SETPRIO = 262144
-ET_ABI_VERSION = 8
+ET_ABI_VERSION = 9
 
 
 class EpipolarAmdError(RuntimeError):
@@ -62,6 +62,7 @@ _SIGNATURES = {
     "et_epipolar_forward": (ctypes.c_int, [_D, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "et_epipolar_forward_workspace_bytes": (ctypes.c_size_t, [_D]),
     "et_epipolar_forward_workspace_stats_offset": (ctypes.c_size_t, [_D]),
+    "et_epipolar_forward_workspace_error_offset": (ctypes.c_size_t, [_D]),
     "et_epipolar_forward_tiled": (ctypes.c_int, [_D] + [_P] * 12 + [ctypes.c_size_t, _P]),
     "et_epipolar_backward_tiled_workspace_bytes": (ctypes.c_size_t, [_D]),
     "et_epipolar_backward_tiled": (ctypes.c_int, [_D, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, ctypes.c_size_t, _P]),

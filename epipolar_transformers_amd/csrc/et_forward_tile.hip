@@ -4,7 +4,9 @@
 
 namespace {
 #include "kernels_forward_tile.inc"     // tile_order_kernel, epipolar_fwd_tile_kernel / _list_kernel
-#include "kernels_forward_tile_ws.inc"  // epipolar_fwd_tile_ws_kernel (warp-specialised, persistent)
+#include "kernels_forward_tile_ws.inc"  // epipolar_fwd_tile_ws_kernel (warp-specialised, persistent; first generation)
+#include "kernels_source_planes.inc"    // source_planes_kernel (the source maps as split-fp16 planes, once per call)
+#include "kernels_forward_tile_ws2.inc" // epipolar_fwd_tile_ws2_kernel (second generation: the default)
 }  // namespace
 #include "et_tile_host.h"
 
@@ -23,7 +25,16 @@ size_t et_epipolar_forward_workspace_bytes(const EtLayerDesc *desc)
 {
     if (validate(desc) || !tile_eligible(desc)) return 0;
     const size_t tiles = (size_t)desc->N * (((size_t)desc->H * desc->W + kTilePix - 1) / kTilePix);
-    return tile_workspace_words(tiles, (size_t)desc->N) * sizeof(int) + 256u;
+    size_t words = tile_workspace_words(tiles, (size_t)desc->N);
+    if (tile_ws2_eligible(desc)) words += tile_workspace_plane_words((size_t)desc->N, (size_t)desc->H * desc->W);
+    return words * sizeof(int) + 256u;
+}
+
+size_t et_epipolar_forward_workspace_error_offset(const EtLayerDesc *desc)
+{
+    if (validate(desc) || !tile_eligible(desc)) return 0;
+    const size_t tiles = (size_t)desc->N * (((size_t)desc->H * desc->W + kTilePix - 1) / kTilePix);
+    return (tiles * kTilePix + 1) * sizeof(int);
 }
 
 size_t et_epipolar_forward_workspace_stats_offset(const EtLayerDesc *desc)
@@ -66,7 +77,7 @@ int et_epipolar_forward_tiled(const EtLayerDesc *desc, const float *xs, const fl
     p.total_blocks = (int)total;
     tp.hw_words = (HW + 31) / 32;
     tp.rows_cap = tile_rows_cap(desc);
-    const TileWorkspace w = carve_tile_workspace(workspace, (size_t)total, (size_t)desc->N);
+    const TileWorkspace w = carve_tile_workspace(workspace, (size_t)total, (size_t)desc->N, (size_t)HW);
     tp.perm = w.perm;
     tp.stats = w.stats;
     tp.tile_list = w.ovf_list;
@@ -77,16 +88,58 @@ int et_epipolar_forward_tiled(const EtLayerDesc *desc, const float *xs, const fl
     const size_t lds_sort = (size_t)n2 * sizeof(unsigned long long);
     const int dev = current_device();
     ET_GRANT_LDS(tile_order_kernel, lds_sort, dev);
+    // (the per-pair scale estimates only for the first-generation kernel; the second scales every row exactly)
+    float *scales = tile_ws_eligible(desc) && !tile_ws2_eligible(desc) ? w.scales : nullptr;
     hipLaunchKernelGGL(tile_order_kernel, dim3(desc->N), dim3(1024), lds_sort, st, *desc, xs, ys, cam, n2,
-                       tp.tiles_per_pair * kTilePix, w.perm, w.ovf_count, feat_ref, feat_src, w.scales, w.segs);
+                       tp.tiles_per_pair * kTilePix, w.perm, w.ovf_count, feat_ref, feat_src, scales, w.segs);
     if (int e = check_launch("et_epipolar_forward_tiled(order)")) return e;
     const int kpl = (desc->K + 63) / 64;
     const int rows = tile_rows(desc);
     const size_t lds = (size_t)(tile_array_floats(rows) + rows + kTilePix + 4 + kTilePix * 4) * 4 +
                        (size_t)tp.hw_words * 8 + (kpl == 1 ? (size_t)kTilePix * kWave * 8 : 0);
 #define ET_SET_LDS(KERNEL, BYTES) ET_GRANT_LDS(KERNEL, BYTES, dev)
+    if (tile_ws2_eligible(desc)) {
+        // 2a. the source maps as split-fp16 planes, one pass over the batch (HBM-bound) ...
+        const long long nrows = (long long)desc->N * HW;
+        const long long pblocks = (nrows + 4 * kPlaneRowsPerWave - 1) / (4 * kPlaneRowsPerWave);
+        if (pblocks > 0x7fffffffLL) return fail("grid too large");
+        hipLaunchKernelGGL(source_planes_kernel, dim3((unsigned)pblocks), dim3(256), 0, st, feat_src, w.planes, w.rowinv, nrows);
+        if (int e = check_launch("et_epipolar_forward_tiled(planes)")) return e;
+        // ... 2b. one persistent block per CU, matrix and vector waves specialised (kernels_forward_tile_ws2.inc) ...
+        TileWs2Params wp;
+        wp.f = p;
+        wp.perm = w.perm;
+        wp.tiles_per_pair = tp.tiles_per_pair;
+        wp.total_tiles = (int)total;
+        wp.rows_cap = tp.rows_cap;
+        wp.ovf_count = w.ovf_count;
+        wp.ovf_list = w.ovf_list;
+        wp.stats = w.stats;
+        wp.err = w.ovf_count + 1;
+        wp.segs = w.segs;
+        wp.planes = w.planes;
+        wp.rowinv = w.rowinv;
+        wp.experiment = 0;
+#ifdef ET_WS_PROFILE
+        wp.prof = g_ws_prof;
+        if (const char *e = getenv("ET_WS_EXPERIMENT")) wp.experiment = atoi(e);
+#else
+        wp.prof = nullptr;
+#endif
+        const int cus = device_cus(dev);
+        const unsigned grid = (unsigned)(total < cus ? total : cus);
+        const size_t lds_ws = tile_ws2_lds_bytes(kTileRowsSmall);
+        ET_SET_LDS((epipolar_fwd_tile_ws2_kernel<kTileRowsSmall>), lds_ws);
+        hipLaunchKernelGGL((epipolar_fwd_tile_ws2_kernel<kTileRowsSmall>), dim3(grid), dim3((kWsMatrixWaves + 8) * kWave), lds_ws, st, wp);
+        if (int e = check_launch("et_epipolar_forward_tiled(ws2)")) return e;
+        // ... 2c. and the tiles it left over (row sets beyond its arrays; normally none) one block per tile
+        const unsigned lgrid = (unsigned)(total < 2LL * cus ? total : 2LL * cus);
+        ET_SET_LDS((epipolar_fwd_tile_list_kernel<1, kTileRowsSmall>), lds);
+        hipLaunchKernelGGL((epipolar_fwd_tile_list_kernel<1, kTileRowsSmall>), dim3(lgrid), dim3(256), lds, st, tp);
+        return check_launch("et_epipolar_forward_tiled(list)");
+    }
     if (tile_ws_eligible(desc)) {
-        // 2a. one persistent block per CU, matrix and vector waves specialised (kernels_forward_tile_ws.inc) ...
+        // 2a'. (ET_VARIANT_WS_V1) the first-generation persistent kernel (kernels_forward_tile_ws.inc) ...
         TileWsParams wp;
         wp.f = p;
         wp.perm = w.perm;
@@ -110,17 +163,11 @@ int et_epipolar_forward_tiled(const EtLayerDesc *desc, const float *xs, const fl
         const int cus = device_cus(dev);
         const unsigned grid = (unsigned)(total < cus ? total : cus);
         const size_t lds_ws = tile_ws_lds_bytes(kTileRowsSmall, tp.hw_words, desc->H, desc->W);
-        if (desc->variant & ET_VARIANT_WS_NV4) {
-            ET_SET_LDS((epipolar_fwd_tile_ws_kernel<kTileRowsSmall, 4>), lds_ws);
-            hipLaunchKernelGGL((epipolar_fwd_tile_ws_kernel<kTileRowsSmall, 4>), dim3(grid), dim3((kWsMatrixWaves + 4) * kWave),
-                               lds_ws, st, wp);
-        } else {
-            ET_SET_LDS((epipolar_fwd_tile_ws_kernel<kTileRowsSmall, 8>), lds_ws);
-            hipLaunchKernelGGL((epipolar_fwd_tile_ws_kernel<kTileRowsSmall, 8>), dim3(grid), dim3((kWsMatrixWaves + 8) * kWave),
-                               lds_ws, st, wp);
-        }
+        ET_SET_LDS((epipolar_fwd_tile_ws_kernel<kTileRowsSmall, 8>), lds_ws);
+        hipLaunchKernelGGL((epipolar_fwd_tile_ws_kernel<kTileRowsSmall, 8>), dim3(grid), dim3((kWsMatrixWaves + 8) * kWave),
+                           lds_ws, st, wp);
         if (int e = check_launch("et_epipolar_forward_tiled(ws)")) return e;
-        // ... 2b. and the tiles it left over (row sets beyond its arrays; normally none) one block per tile
+        // ... 2b'. and the tiles it left over one block per tile
         const unsigned lgrid = (unsigned)(total < 2LL * cus ? total : 2LL * cus);
         ET_SET_LDS((epipolar_fwd_tile_list_kernel<1, kTileRowsSmall>), lds);
         hipLaunchKernelGGL((epipolar_fwd_tile_list_kernel<1, kTileRowsSmall>), dim3(lgrid), dim3(256), lds, st, tp);

@@ -21,6 +21,25 @@ __device__ __forceinline__ void split_f16_pair(float v0, float v1, unsigned &hi,
     lo = __builtin_bit_cast(unsigned, f16x2_t{(_Float16)l0, (_Float16)l1});
 }
 
+// The same split with both halves of a value kept in ONE dword, ( hi | lo << 16 ): hi = RN16(v) (v_cvt_pk_f16_f32, round
+// to nearest: |v - hi| <= 2^-12 |v|), lo = RN16(v - hi) (the remainder is exact in fp32), so hi + lo carries >= 22
+// significant bits of v while |lo| stays above fp16's subnormal range, and 2^-25 of the scale's range below it.  With the
+// other operand held the same way, ( hi', lo' ),
+//     mfma(a, b) + mfma(a, rot16(b))  =  sum_k  (hi'_k hi_k + lo'_k lo_k) + (hi'_k lo_k + lo'_k hi_k)  =  sum_k a_k b_k
+// -- all four cross terms from TWO fp16 MFMAs, and one v_alignbit per operand dword instead of a conversion.
+// 2.5 instructions per value (the second conversion re-derives hi: same instruction, same rounding, same bits).
+__device__ __forceinline__ void split_hilo_pair(float v0, float v1, unsigned &d0, unsigned &d1)
+{
+    typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
+    typedef float f32x2_t __attribute__((ext_vector_type(2)));
+    const unsigned h2 = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2_t{v0, v1}, f16x2_t));
+    float l0, l1;
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(l0) : "v"(h2), "v"(v0));
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(l1) : "v"(h2), "v"(v1));
+    d0 = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2_t{v0, l0}, f16x2_t));
+    d1 = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2_t{v1, l1}, f16x2_t));
+}
+
 // eight scaled fp32 values -> fp16 hi and lo; amax tracks the largest magnitude seen (the overflow guard)
 template <bool GUARD>
 __device__ __forceinline__ void split_f16x8(const float (&v)[8], f16x8 &hi, f16x8 &lo, float &amax)

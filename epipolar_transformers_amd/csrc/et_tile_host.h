@@ -28,8 +28,8 @@ bool tile_eligible(const EtLayerDesc *d)
     return tile_rows_per_pixel(d) <= tile_rows_cap(d);
 }
 
-// the warp-specialised persistent kernel: lanes <-> samples (K <= 64), 256-row arrays.  Soft-max on only: its second
-// GEMM converts the B rows (attention x bilinear weights, <= 1 with the soft-max) to fp16 without a guard; with
+// the warp-specialised persistent kernels: lanes <-> samples (K <= 64), 256-row arrays.  Soft-max on only: their second
+// GEMM holds the B rows (attention x bilinear weights, <= 1 with the soft-max) in fp16 pairs; with
 // EPIPOLAR.SOFTMAX_ENABLED False the "attention" is sim / K -- unbounded, -1e10 / K on masked samples -- and the call
 // takes the exact-fp32 one-block-per-tile kernel.
 bool tile_ws_eligible(const EtLayerDesc *d)
@@ -37,17 +37,27 @@ bool tile_ws_eligible(const EtLayerDesc *d)
     return !(d->variant & ET_VARIANT_TILE_CLASSIC) && d->softmax_enabled && d->K <= 64 && d->W >= 2 &&
            tile_rows(d) == kTileRowsSmall;
 }
+// second generation (pre-split source planes, row masks: kernels_forward_tile_ws2.inc): the default where it applies
+bool tile_ws2_eligible(const EtLayerDesc *d)
+{
+    return tile_ws_eligible(d) && !(d->variant & ET_VARIANT_WS_V1) && d->W <= 64 && d->H <= 64;
+}
 
 // Workspace of the tile forward (all int32, base aligned up to 256 bytes):
-//   perm[tiles * 32] | overflow count (64 words) | overflow list[tiles] | stats[tiles] | scales[4 * N] (float) |
-//   segments[tiles * 32] (float4, 16-byte aligned)
+//   perm[tiles * 32] | overflow count, [1] sticky error word (64 words) | overflow list[tiles] | stats[tiles] |
+//   scales[4 * N] (float) | segments[tiles * 32] (float4, 16-byte aligned) |
+//   -- warp-specialised kernel, second generation only: --
+//   rowinv[N * HW] (float) | planes[N * HW * 256] (dwords, 256-byte aligned)
 struct TileWorkspace {
     int *perm, *ovf_count, *ovf_list, *stats;
     float *scales;
     float4 *segs;
+    float *rowinv;
+    unsigned *planes;
 };
 size_t tile_workspace_words(size_t tiles, size_t pairs) { return tiles * kTilePix + 64 + 2 * tiles + 4 * pairs + 4 + 4 * tiles * kTilePix; }
-TileWorkspace carve_tile_workspace(void *workspace, size_t tiles, size_t pairs)
+size_t tile_workspace_plane_words(size_t pairs, size_t hw) { return pairs * hw + 64 + pairs * hw * 256; }
+TileWorkspace carve_tile_workspace(void *workspace, size_t tiles, size_t pairs, size_t hw = 0)
 {
     TileWorkspace w;
     w.perm = reinterpret_cast<int *>((reinterpret_cast<uintptr_t>(workspace) + 255) & ~(uintptr_t)255);
@@ -56,6 +66,8 @@ TileWorkspace carve_tile_workspace(void *workspace, size_t tiles, size_t pairs)
     w.stats = w.ovf_list + tiles;
     w.scales = reinterpret_cast<float *>(w.stats + tiles);
     w.segs = reinterpret_cast<float4 *>((reinterpret_cast<uintptr_t>(w.scales + 4 * pairs) + 15) & ~(uintptr_t)15);
+    w.rowinv = reinterpret_cast<float *>(w.segs + tiles * kTilePix);
+    w.planes = reinterpret_cast<unsigned *>((reinterpret_cast<uintptr_t>(w.rowinv + pairs * hw) + 255) & ~(uintptr_t)255);
     return w;
 }
 }  // namespace

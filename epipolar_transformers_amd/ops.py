@@ -120,7 +120,7 @@ def sample_locs(spec: LayerSpec, cam: torch.Tensor) -> torch.Tensor:
     return out
 
 
-_TILE_BITS = (_lib.ET_VARIANT_TILE_SPLIT | _lib.ET_VARIANT_TILE_CLASSIC | _lib.ET_VARIANT_WS_NV4 |
+_TILE_BITS = (_lib.ET_VARIANT_TILE_SPLIT | _lib.ET_VARIANT_TILE_CLASSIC | _lib.ET_VARIANT_WS_V1 |
               _lib.ET_VARIANT_WS_SETPRIO)      # variant bits that tune the tile path instead of leaving it
 
 
@@ -154,6 +154,10 @@ def forward_nhwc(spec: LayerSpec, ref: torch.Tensor, src: torch.Tensor, cam: tor
     with torch.cuda.device(ref.device):
         if ws_bytes > 0:
             ws = workspace if workspace is not None else _workspace(ref.device, ws_bytes, "fwd")
+            if workspace is None:
+                dev = torch.device(ref.device)
+                _last_desc[(dev.type, dev.index if dev.index is not None else torch.cuda.current_device(),
+                            torch.cuda.current_stream(dev).cuda_stream, "fwd")] = d
             if ws.numel() < ws_bytes or ws.device != ref.device:
                 raise ValueError("workspace of %d bytes on %s: need %d on %s" % (ws.numel(), ws.device, ws_bytes, ref.device))
             _lib.check(lib.et_epipolar_forward_tiled(ctypes.byref(d), _ptr(xs), _ptr(ys), _ptr(steps), _ptr(cam),
@@ -185,8 +189,33 @@ def _workspace(device, nbytes: int, tag: str = "bwd") -> torch.Tensor:
            torch.cuda.current_stream(dev).cuda_stream, tag)
     buf = _workspaces.get(key)
     if buf is None or buf.numel() < nbytes:
-        _workspaces[key] = buf = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        # zero-initialised ONCE (include/epipolar_amd.h): the tile forward keeps a sticky error word in it
+        _workspaces[key] = buf = torch.zeros(nbytes, dtype=torch.uint8, device=device)
     return buf
+
+
+def check_tile_errors(spec: "LayerSpec" = None, n: int = None, c: int = 256, workspace: torch.Tensor = None):
+    """Read the sticky error word(s) the tile forward leaves in its workspace (the library never synchronises, so this
+    is where a device-side fault surfaces: it synchronises).  Without arguments: every cached forward workspace,
+    assuming the last shape it was used with; with (spec, n, c, workspace): that one.  Raises EpipolarAmdError."""
+    todo = []
+    if workspace is not None:
+        todo.append((workspace, spec.desc(n, c)))
+    else:
+        todo = [(buf, d) for (key, buf), d in ((kv, _last_desc.get(kv[0])) for kv in _workspaces.items()) if d is not None]
+    lib = _lib.load()
+    for buf, d in todo:
+        off = int(lib.et_epipolar_forward_workspace_error_offset(ctypes.byref(d)))
+        if off == 0:
+            continue
+        base = (-buf.data_ptr()) % 256
+        word = int(buf[base + off: base + off + 4].view(torch.int32).item())
+        if word:
+            raise _lib.EpipolarAmdError("the tile forward reported device-side error bits 0x%x (bit 0: a wave gave up "
+                                        "at the kernel's internal barrier; the results of that call are invalid)" % word)
+
+
+_last_desc = {}
 
 
 def release_workspaces():

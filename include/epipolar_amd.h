@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define ET_ABI_VERSION 8
+#define ET_ABI_VERSION 9
 
 /* Static description of one layer call: the cfg keys the reference reads in
  * Epipolar.__init__ (epipolar.py:12-54) and at call time (epipolar.py:303-311,
@@ -79,8 +79,8 @@ typedef struct EtLayerDesc {
 #define ET_VARIANT_NO_TILE 16384  /* host wrappers: do not route C == 256 calls to et_epipolar_forward_tiled */
 #define ET_VARIANT_TILE_SPLIT 32768 /* et_epipolar_forward_tiled, testing: 64-row tiles, so that tiles overflow and split */
 #define ET_VARIANT_TILE_CLASSIC 65536 /* et_epipolar_forward_tiled: the one-block-per-tile kernel instead of the warp-specialised persistent one */
-#define ET_VARIANT_WS_NV4 131072  /* warp-specialised kernel, tuning: 4 vector waves per block instead of 8 */
-#define ET_VARIANT_WS_SETPRIO 262144 /* warp-specialised kernel, tuning: s_setprio 1 on the matrix waves */
+#define ET_VARIANT_WS_V1 131072   /* et_epipolar_forward_tiled: the first-generation warp-specialised kernel (per-pair scale estimates, source rows converted where they are used) instead of the second (pre-split source planes) */
+#define ET_VARIANT_WS_SETPRIO 262144 /* first-generation warp-specialised kernel, tuning: s_setprio 1 on the matrix waves */
 #define ET_VARIANT_BASELINE 256    /* batches of 8, compiler-chosen registers, pixels 4w..4w+3 per wave   */
 /* Bits 64 and 128 are reserved: in development builds of the library (-DET_DEV_ABLATE) they switch the per-pixel
  * kernel's tap loads off for roofline ablations (wrong results by construction); a product build rejects them. */
@@ -119,21 +119,32 @@ int et_epipolar_forward(const EtLayerDesc *desc, const float *xs, const float *y
 
 /* The same operator in its MFMA tile formulation (C == 256 head): reference pixels are ordered by
  * their epipolar line, 32 neighbouring lines form a tile, and the channel-long work of the tile runs
- * as two fp32 GEMMs on the matrix cores against the union of the source rows the tile touches
- * (each source row is fetched per tile, not per pixel).  For K <= 64 on maps up to 64 x 64 the tiles
- * are walked by one persistent block per compute unit whose waves are specialised (matrix waves run
- * the two GEMMs of consecutive tiles back to back, vector waves do the geometry / soft-max work of the
- * neighbouring tiles meanwhile); other shapes run one block per tile.  Same arguments and results as
+ * as two GEMMs on the matrix cores against the union of the source rows the tile touches (each source
+ * row is fetched per tile, not per pixel).  For K <= 64 on maps up to 64 x 64 with the soft-max on
+ * (every headline config) the call is: one pass that rewrites the source maps as split-fp16 planes
+ * (one dword ( hi | lo << 16 ) per value, one exact power-of-two scale per pixel row; kept in the
+ * workspace), then one persistent block per compute unit whose waves are specialised (matrix waves run
+ * the two GEMMs of consecutive tiles back to back as fp16 MFMAs with fp32 accumulation, ~22
+ * significant bits per product; vector waves do the geometry / soft-max work of the neighbouring tiles
+ * meanwhile).  Other shapes run one block per tile in exact fp32.  Same arguments and results as
  * et_epipolar_forward (rounding differs at the 1e-6 level: the sums are re-associated), plus
  *   workspace : device scratch of at least et_epipolar_forward_workspace_bytes(desc) bytes, 256-byte
- *               aligned: the per-pair pixel order, the overflow-tile list and one int32 of statistics
- *               per tile ( U | groups << 16 : size of the tile's source-row set, number of groups it
- *               was split into) starting et_epipolar_forward_workspace_stats_offset(desc) bytes in --
- *               readable by the caller after the call, in tile order (pair-major).
+ *               aligned, ZERO-INITIALISED ONCE by the caller when it is allocated: the per-pair pixel
+ *               order, the overflow-tile list, the source planes (as large as feat_src) and
+ *                 - one int32 of statistics per tile ( U | groups << 16 : size of the tile's
+ *                   source-row set, number of groups it was split into) starting
+ *                   et_epipolar_forward_workspace_stats_offset(desc) bytes in, in tile order
+ *                   (pair-major), readable by the caller after the call;
+ *                 - one STICKY int32 error word et_epipolar_forward_workspace_error_offset(desc) bytes
+ *                   in: the kernels only ever OR bits into it (bit 0: a wave of the persistent kernel
+ *                   gave up waiting at its internal barrier -- results of that call are invalid).  The
+ *                   library never synchronises, so the caller reads it when it synchronises anyway
+ *                   (the Python binding: ops.check_tile_errors) -- no error is swallowed silently.
  * et_epipolar_forward_workspace_bytes returns 0 when the tile path does not apply to `desc`
  * (then et_epipolar_forward_tiled fails and et_epipolar_forward is the path to call). */
 size_t et_epipolar_forward_workspace_bytes(const EtLayerDesc *desc);
 size_t et_epipolar_forward_workspace_stats_offset(const EtLayerDesc *desc);
+size_t et_epipolar_forward_workspace_error_offset(const EtLayerDesc *desc);
 int et_epipolar_forward_tiled(const EtLayerDesc *desc, const float *xs, const float *ys, const float *steps,
                               const float *cam, const float *feat_ref, const float *feat_src, float *out,
                               float *attn, float *corr_pos, const float *res_bias, float *res_base,

@@ -20,7 +20,7 @@ if not hasattr(raw, "et_dev_ws_profile"):
     raise SystemExit("not a profiling build")
 dev = torch.device("cuda:0")
 variant = int(os.environ.get("PROF_VARIANT", 0))
-nv = 4 if variant & _lib.ET_VARIANT_WS_NV4 else 8
+nv = 8
 H, C, K = 64, 256, 64
 P1, P2 = syn.make_pairs(32, 4, H * 4, seed=1000, jitter=(0.05, 8.0))
 g = torch.Generator(device=dev).manual_seed(0)

@@ -175,15 +175,27 @@ def test_tile_path_eligibility_is_decided_on_the_host(lib):
         return (int(lib.et_epipolar_forward_workspace_bytes(ctypes.byref(d))),
                 int(lib.et_epipolar_backward_tiled_workspace_bytes(ctypes.byref(d))))
 
-    def ws_bytes(tiles, pairs=3):   # pixel order (32 per tile) | overflow counter (64 words) | overflow list | statistics | scales | segments
-        return (tiles * 32 + 64 + 2 * tiles + 4 * pairs + 4 + 4 * tiles * 32) * 4 + 256
+    def ws_bytes(tiles, pairs=3, plane_hw=0):
+        # pixel order (32 per tile) | overflow counter + sticky error word (64 words) | overflow list | statistics | scales |
+        # segments [| 1 / scale of every source row | alignment | source planes: the warp-specialised kernel (K <= 64, maps
+        # up to 64 x 64, soft-max on) keeps the source maps as split-fp16 dwords, as large as feat_src]
+        words = tiles * 32 + 64 + 2 * tiles + 4 * pairs + 4 + 4 * tiles * 32
+        if plane_hw:
+            words += pairs * plane_hw + 64 + pairs * plane_hw * 256
+        return words * 4 + 256
 
     fwd, bwd = sizes(64, 64, 64, 256)                       # configs[1]
-    assert fwd == bwd == ws_bytes(3 * 128)
+    assert fwd == bwd == ws_bytes(3 * 128, plane_hw=64 * 64)
+    assert sizes(64, 64, 64, 256, variant=_lib.ET_VARIANT_WS_V1)[0] == ws_bytes(3 * 128)       # first-generation kernel: no planes
+    assert sizes(64, 64, 64, 256, variant=_lib.ET_VARIANT_TILE_CLASSIC)[0] == ws_bytes(3 * 128)
+    assert ops.LayerSpec(H=64, W=64, K=64, softmax_enabled=False).desc(3, 256) is not None
+    d_ns = ops.LayerSpec(H=64, W=64, K=64, softmax_enabled=False).desc(3, 256)
+    assert int(lib.et_epipolar_forward_workspace_bytes(ctypes.byref(d_ns))) == ws_bytes(3 * 128)   # soft-max off: exact-fp32 tiles
     assert sizes(96, 96, 64, 256)[0] == ws_bytes(3 * 288)           # config 4: 384-row tiles
-    assert sizes(10, 10, 16, 256)[0] == ws_bytes(3 * 4)             # 100 pixels -> 4 padded tiles
+    assert sizes(10, 10, 16, 256)[0] == ws_bytes(3 * 4, plane_hw=100)   # 100 pixels -> 4 padded tiles
     d = ops.LayerSpec(H=64, W=64, K=64).desc(3, 256)
     assert int(lib.et_epipolar_forward_workspace_stats_offset(ctypes.byref(d))) == (3 * 128 * 32 + 64 + 3 * 128) * 4
+    assert int(lib.et_epipolar_forward_workspace_error_offset(ctypes.byref(d))) == (3 * 128 * 32 + 1) * 4
     assert sizes(64, 64, 64, 128) == (0, 0)                 # other channel counts: per-pixel kernels
     f5, b5 = sizes(128, 128, 128, 256)
     assert f5 == b5 == ws_bytes(3 * 512)                    # config 5: 512-row tiles, K = 128 (two samples per lane)
