@@ -263,7 +263,7 @@ def main():
     # is carried beside it against the dense fp32 peak (157.3 TFLOP/s, vector = matrix).  In EXACT fp32 the 50 %-of-HBM
     # target is not reachable: the 92 GFLOP of fp32 MFMAs the tiles issue take 0.59 ms at peak (> 0.437 ms).
     d_ = spec.desc(n_pairs, C)
-    tile_bits = (_lib.ET_VARIANT_TILE_CLASSIC | _lib.ET_VARIANT_WS_V1 | _lib.ET_VARIANT_WS_SETPRIO)
+    tile_bits = (_lib.ET_VARIANT_TILE_CLASSIC | _lib.ET_VARIANT_WS_V2 | _lib.ET_VARIANT_WS_SETPRIO)
     tiled = (args.variant & ~tile_bits) == 0 and int(_lib.load().et_epipolar_forward_workspace_bytes(ctypes.byref(d_))) > 0
     split = tiled and not (args.variant & _lib.ET_VARIANT_TILE_CLASSIC) and K <= 64 and H <= 64 and W <= 64
     traffic, traffic_src = measured_hbm_traffic(C, H, W, K, n_pairs), "profiles/fwd_pmc_latest.json (rocprofv3 --pmc pass, committed)"

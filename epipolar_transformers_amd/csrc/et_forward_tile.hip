@@ -99,7 +99,7 @@ int et_epipolar_forward_tiled(const EtLayerDesc *desc, const float *xs, const fl
                        (size_t)tp.hw_words * 8 + (kpl == 1 ? (size_t)kTilePix * kWave * 8 : 0);
 #define ET_SET_LDS(KERNEL, BYTES) ET_GRANT_LDS(KERNEL, BYTES, dev)
     if (tile_ws2_eligible(desc)) {
-        // 2a. the source maps as split-fp16 planes, one pass over the batch (HBM-bound) ...
+        // 2a. (ET_VARIANT_WS_V2) the source maps as split-fp16 planes, one pass over the batch (HBM-bound) ...
         const long long nrows = (long long)desc->N * HW;
         const long long pblocks = (nrows + 4 * kPlaneRowsPerWave - 1) / (4 * kPlaneRowsPerWave);
         if (pblocks > 0x7fffffffLL) return fail("grid too large");
@@ -139,7 +139,7 @@ int et_epipolar_forward_tiled(const EtLayerDesc *desc, const float *xs, const fl
         return check_launch("et_epipolar_forward_tiled(list)");
     }
     if (tile_ws_eligible(desc)) {
-        // 2a'. (ET_VARIANT_WS_V1) the first-generation persistent kernel (kernels_forward_tile_ws.inc) ...
+        // 2a'. the first-generation persistent kernel (kernels_forward_tile_ws.inc): the default ...
         TileWsParams wp;
         wp.f = p;
         wp.perm = w.perm;

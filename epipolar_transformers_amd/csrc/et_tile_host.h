@@ -37,10 +37,12 @@ bool tile_ws_eligible(const EtLayerDesc *d)
     return !(d->variant & ET_VARIANT_TILE_CLASSIC) && d->softmax_enabled && d->K <= 64 && d->W >= 2 &&
            tile_rows(d) == kTileRowsSmall;
 }
-// second generation (pre-split source planes, row masks: kernels_forward_tile_ws2.inc): the default where it applies
+// second generation (pre-split source planes with exact per-row scales, row masks: kernels_forward_tile_ws2.inc), on
+// request (ET_VARIANT_WS_V2): measured slower than the first on MI355X (profiles/r03_ws2_*), kept as the variant whose
+// arithmetic needs no scale estimate at all
 bool tile_ws2_eligible(const EtLayerDesc *d)
 {
-    return tile_ws_eligible(d) && !(d->variant & ET_VARIANT_WS_V1) && d->W <= 64 && d->H <= 64;
+    return tile_ws_eligible(d) && (d->variant & ET_VARIANT_WS_V2) && d->W <= 64 && d->H <= 64;
 }
 
 // Workspace of the tile forward (all int32, base aligned up to 256 bytes):

@@ -120,7 +120,7 @@ def sample_locs(spec: LayerSpec, cam: torch.Tensor) -> torch.Tensor:
     return out
 
 
-_TILE_BITS = (_lib.ET_VARIANT_TILE_SPLIT | _lib.ET_VARIANT_TILE_CLASSIC | _lib.ET_VARIANT_WS_V1 |
+_TILE_BITS = (_lib.ET_VARIANT_TILE_SPLIT | _lib.ET_VARIANT_TILE_CLASSIC | _lib.ET_VARIANT_WS_V2 |
               _lib.ET_VARIANT_WS_SETPRIO)      # variant bits that tune the tile path instead of leaving it
 
 

@@ -22,7 +22,7 @@ def events_ms(fn, reps=20, warm=3):
     torch.cuda.synchronize()
     t = sorted(a.elapsed_time(b) for a, b in ev)
     return sum(t) / len(t), t[0]
-for name, v in (("ws2 default", 0), ("ws v1", _lib.ET_VARIANT_WS_V1), ("classic fp32", _lib.ET_VARIANT_TILE_CLASSIC)):
+for name, v in (("ws2 default", 0), ("ws v1", _lib.ET_VARIANT_WS_V2), ("classic fp32", _lib.ET_VARIANT_TILE_CLASSIC)):
     spec = ops.LayerSpec(H=H, W=H, K=K, variant=v)
     m, lo = events_ms(lambda: ops.forward_nhwc(spec, ref, src, cam))
     print("%-16s forward call %.3f ms (min %.3f)" % (name, m, lo), flush=True)

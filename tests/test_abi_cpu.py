@@ -185,14 +185,14 @@ def test_tile_path_eligibility_is_decided_on_the_host(lib):
         return words * 4 + 256
 
     fwd, bwd = sizes(64, 64, 64, 256)                       # configs[1]
-    assert fwd == bwd == ws_bytes(3 * 128, plane_hw=64 * 64)
-    assert sizes(64, 64, 64, 256, variant=_lib.ET_VARIANT_WS_V1)[0] == ws_bytes(3 * 128)       # first-generation kernel: no planes
-    assert sizes(64, 64, 64, 256, variant=_lib.ET_VARIANT_TILE_CLASSIC)[0] == ws_bytes(3 * 128)
-    assert ops.LayerSpec(H=64, W=64, K=64, softmax_enabled=False).desc(3, 256) is not None
-    d_ns = ops.LayerSpec(H=64, W=64, K=64, softmax_enabled=False).desc(3, 256)
+    assert fwd == bwd == ws_bytes(3 * 128)
+    # the second-generation warp-specialised kernel (on request) also keeps the source maps as split-fp16 planes
+    assert sizes(64, 64, 64, 256, variant=_lib.ET_VARIANT_WS_V2)[0] == ws_bytes(3 * 128, plane_hw=64 * 64)
+    assert sizes(64, 64, 64, 256, variant=_lib.ET_VARIANT_TILE_CLASSIC | _lib.ET_VARIANT_WS_V2)[0] == ws_bytes(3 * 128)
+    d_ns = ops.LayerSpec(H=64, W=64, K=64, softmax_enabled=False, variant=_lib.ET_VARIANT_WS_V2).desc(3, 256)
     assert int(lib.et_epipolar_forward_workspace_bytes(ctypes.byref(d_ns))) == ws_bytes(3 * 128)   # soft-max off: exact-fp32 tiles
     assert sizes(96, 96, 64, 256)[0] == ws_bytes(3 * 288)           # config 4: 384-row tiles
-    assert sizes(10, 10, 16, 256)[0] == ws_bytes(3 * 4, plane_hw=100)   # 100 pixels -> 4 padded tiles
+    assert sizes(10, 10, 16, 256)[0] == ws_bytes(3 * 4)             # 100 pixels -> 4 padded tiles
     d = ops.LayerSpec(H=64, W=64, K=64).desc(3, 256)
     assert int(lib.et_epipolar_forward_workspace_stats_offset(ctypes.byref(d))) == (3 * 128 * 32 + 64 + 3 * 128) * 4
     assert int(lib.et_epipolar_forward_workspace_error_offset(ctypes.byref(d))) == (3 * 128 * 32 + 1) * 4

@@ -251,7 +251,7 @@ def _full_inputs(frames, views, H, C, image, seed):
 @pytest.mark.parametrize("shape", [dict(H=64, C=256, K=64, image=256, views=4, name="config2 R50 256x256"),
                                    dict(H=96, C=256, K=64, image=384, views=4, name="config4 R152 384x384"),
                                    dict(H=128, C=256, K=128, image=512, views=8, name="config5 stress")])
-@pytest.mark.parametrize("variant", [0, 16384, 28, 1024, 2048, 256])
+@pytest.mark.parametrize("variant", [0, 131072, 16384, 28, 1024, 2048, 256])
 def test_full_shape_pairs_vs_oracle(env, oracle_mod, shape, variant):
     """BASELINE.json configs 2/4/5 at their real C, HxW and K, on a few pairs the
     oracle finishes in seconds (full tensors compared)."""
@@ -260,7 +260,8 @@ def test_full_shape_pairs_vs_oracle(env, oracle_mod, shape, variant):
     P1, P2, f1, f2 = _full_inputs(1, shape["views"], H, C, shape["image"], seed=11)
     P1, P2, f1, f2 = P1[:2], P2[:2], f1[:2], f2[:2]
     f1[0, :, 5, 7] = 0
-    # 0: default (MFMA tiles where eligible: configs 2 and 4), 16384: default per-pixel kernel (4 pixels/wave
+    # 0: default (MFMA tiles where eligible: configs 2 and 4), 131072: the second-generation warp-specialised tile
+    # kernel (pre-split source planes; config 2 only, else the default), 16384: default per-pixel kernel (4 pixels/wave
     # at C=256, K<=64), 28: 1 pixel/wave
     spec = ops.LayerSpec(H=H, W=H, K=K, variant=variant)
     cam = camera.pair_algebra(P1, P2).cuda()
@@ -302,7 +303,7 @@ def test_config2_full_batch_properties(env):
     out2, attn2, corr2 = ops.forward_nhwc(spec, ref, src, cam)
     assert torch.equal(out, out2) and torch.equal(attn, attn2) and torch.equal(corr, corr2)
     # (3) all variants agree
-    for v in (1, 2, 3, 28, 1024, 2048, 256):
+    for v in (131072, 65536, 1, 2, 3, 28, 1024, 2048, 256):
         spec_v = ops.LayerSpec(H=64, W=64, K=64, variant=v)
         out_v, attn_v, _ = ops.forward_nhwc(spec_v, ref, src, cam)
         assert (out_v - out).abs().max().item() <= 1e-5 and (attn_v - attn).abs().max().item() <= 3e-6   # (spec: 1e-4 / 1e-5 vs the reference)
@@ -413,7 +414,7 @@ def test_mpjpe_delta_vs_reference_pipeline(env):
                                    dict(H=7, W=13, C=12, K=70), dict(H=5, W=6, C=260, K=8),
                                    dict(H=32, W=32, C=256, K=128), dict(H=20, W=24, C=256, K=200),
                                    dict(H=128, W=128, C=256, K=48)])
-@pytest.mark.parametrize("variant", [0, 32768, 16384, 28, 2048, 1024])
+@pytest.mark.parametrize("variant", [0, 131072, 32768, 16384, 28, 2048, 1024])
 def test_ragged_shapes_vs_oracle(env, oracle_mod, shape, variant):
     """Non-square maps, H*W not a multiple of the 16-pixel block / 32-pixel tile (partial blocks, padded tiles),
     K not a multiple of the batch, K > 64 on the tile path, C below/above one wave of float4 -- forward,
@@ -423,6 +424,8 @@ def test_ragged_shapes_vs_oracle(env, oracle_mod, shape, variant):
     from epipolar_transformers_amd import synthetic as syn
 
     H, W, C, K = shape["H"], shape["W"], shape["C"], shape["K"]
+    if variant == 131072 and (C != 256 or K > 64 or max(H, W) > 64):
+        pytest.skip("the second-generation warp-specialised kernel covers C=256, K <= 64, maps up to 64 x 64")
     if variant == 32768 and (C != 256 or 4 * min(K, max(H, W)) > 64):
         pytest.skip("64-row tile splitting applies to C=256 with 4*min(K, max(H,W)) <= 64")
     if H * W >= 16384 and variant not in (0, 16384):
@@ -446,7 +449,7 @@ def test_ragged_shapes_vs_oracle(env, oracle_mod, shape, variant):
     _assert_corr_pos(ops, spec, cam.cuda(), corr.cpu().numpy(), want["corr_pos"], attn.cpu().numpy(), max_frac=5e-2)
     assert np.array_equal(ops.sample_locs(spec, cam.cuda()).cpu().numpy(), want["sample_locs"])
     g1, g2 = oracle_mod.backward(so, f1.numpy(), f2.numpy(), want["sample_locs"], go.numpy())
-    forms = ["gather", "atomic"] + (["tile"] if C == 256 and variant in (0, 32768) else [])
+    forms = ["gather", "atomic"] + (["tile"] if C == 256 and variant in (0, 131072, 32768) else [])
     for form in forms:
         gr, gs = ops.backward_nhwc(spec, ref, src, cam.cuda(), ops.to_nhwc(go.cuda()), form=form)
         for got, wantg in ((gr, g1), (gs, g2)):
