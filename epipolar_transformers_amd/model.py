@@ -15,9 +15,9 @@ What changes against the reference:
     the highest score -- here all (reference, source) combinations go through ONE launch of the fused layer.
   * `BACKBONE.SYNC_BN` converts through `parallel.convert_sync_batchnorm` (model.py:56-58).
 
-The batch-dict keys are the reference's (model.py:166-207).  Training returns the reference's loss dict entry
-(`stage_loss0`, JointsMSELoss of modeling/metrics/metrics2d.py) so a training loop written against Modelbuilder
-keeps working for this task."""
+The batch-dict keys are the reference's (model.py:166-207).  Training returns the reference's loss dict (`loss`: the
+JointsMSELoss of modeling/metrics/metrics2d.py, renamed from `stage_loss0` as model.py:482-484 does for a single entry)
+so a training loop written against Modelbuilder keeps working for this task."""
 from __future__ import annotations
 
 import torch
@@ -123,7 +123,8 @@ class MultiViewPoseModel(nn.Module):
         """The multiview_keypoint branch of Modelbuilder.forward (model.py:160-302).  `inputs` holds the reference's
         keys: img, KRT, and either `other_index` (rows of the source views inside `img`: the de-duplicated path) or
         `other_img` + `other_KRT` (the reference's two-pass form); optional heatmap / visibility (loss) and points-3d
-        (MPJPE).  Returns (loss_dict, metric_dict) in training, (metric_dict, out) otherwise, as the reference does."""
+        (MPJPE).  Returns (loss_dict, metric_dict) in training, (loss_dict, metric_dict, out) otherwise, as the reference does
+        (model.py:478-493)."""
         cfg = self.cfg
         img = inputs["img"]
         KRT = inputs["KRT"].to(torch.float32)                               # model.py:183-185
@@ -147,7 +148,9 @@ class MultiViewPoseModel(nn.Module):
             vis = inputs.get("visibility")
             vis = torch.ones(heat[0].shape[:2], device=heat[0].device) if vis is None else vis.to(torch.float32)
             loss_dict["stage_loss0"] = self.criterion(heat[0], inputs["heatmap"].to(torch.float32), vis)   # model.py:253
-        out.update(batch_locs=batch_locs, batch_scos=batch_scos, corr_pos=corr_pos, depth=depths,
+        # the reference's keys (model.py:362-373: heatmap_pred, corr_pos, depth, batch_locs, score_pred) + two aliases
+        out.update(heatmap_pred=heat[-1] if heat is not None else None, corr_pos=corr_pos, depth=depths,
+                   batch_locs=batch_locs, score_pred=batch_scos, batch_scos=batch_scos,
                    heatmaps=heat[0] if heat is not None else None)
         if not is_train and cfg.VIS.MULTIVIEW:
             pred = self.lift(batch_locs, batch_scos, KRT, views)
@@ -155,4 +158,12 @@ class MultiViewPoseModel(nn.Module):
             if inputs.get("points-3d") is not None:
                 gt = inputs["points-3d"].to(pred.device).view(-1, views, pred.shape[1], 3)[:, 0]
                 metric_dict["MPJPE"] = mpjpe(pred, gt)                      # metrics3d.py:5-46
-        return (loss_dict, metric_dict) if is_train else (metric_dict, out)
+        # model.py:478-493: several losses are summed into 'loss', a single one is RENAMED to 'loss'; training returns
+        # (loss_dict, metric_dict), evaluation (loss_dict, metric_dict, out) with the empty entries of `out` dropped
+        if len(loss_dict) > 1:
+            loss_dict["loss"] = sum(loss_dict.values())
+        elif len(loss_dict) == 1:
+            loss_dict["loss"] = loss_dict.popitem()[1]
+        if is_train:
+            return loss_dict, metric_dict
+        return loss_dict, metric_dict, {k: v for k, v in out.items() if v is not None}

@@ -109,3 +109,24 @@ def test_launcher_swaps_operator_into_reference_backbone(tmp_path, monkeypatch):
     assert sorted(k for k in net.state_dict() if k.startswith("epipolar_sampler")) == sorted(
         "epipolar_sampler." + k for k in ("z.weight", "z.bias", "bn.weight", "bn.bias", "bn.running_mean",
                                           "bn.running_var", "bn.num_batches_tracked"))
+
+
+def test_backbone_trunk_equals_the_reference_modelbuilder_fixture():
+    """Row N1 on the CPU: the pre-fusion features of our `epipolarposeR-18` (single-view call, resnet.py:381-383,406)
+    equal what the REAL reference `Modelbuilder` produced for the same images and the same (name-derived) weights --
+    tests/golden/model_r18.npz, made by tests/golden/make_model_golden.py.  (The multi-view outputs of the fixture need
+    the GPU layer: tests/test_gpu_model.py.)"""
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    from model_weights import deterministic_state_dict
+
+    d = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "model_r18.npz"))
+    frames, V, size, hs, K, J = [int(v) for v in d["meta"]]
+    cfg = _cfg(size=size)
+    cfg.merge_from_list(["EPIPOLAR.SAMPLESIZE", K, "KEYPOINT.NUM_PTS", J])
+    net = backbones.build_backbone(cfg).eval()
+    net.load_state_dict(deterministic_state_dict(net.state_dict()))
+    with torch.no_grad():
+        feat = net(torch.from_numpy(d["img"]))[0]
+    assert abs(feat.abs().max().item() - float(d["feat_norm"][0])) <= 1e-4 * float(d["feat_norm"][0])
+    assert abs(feat.norm().item() - float(d["feat_norm"][1])) <= 1e-5 * float(d["feat_norm"][1])
+    assert np.abs(feat[:, :8].numpy() - d["feat_slice"]).max() <= 2e-5

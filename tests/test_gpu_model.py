@@ -55,15 +55,15 @@ def test_trunk_once_per_view_equals_the_two_pass_reference_form():
     assert (one[5] - two[5]).abs().max().item() <= 1e-5 and (one[4] != two[4]).any(-1).float().mean().item() <= 1e-2
     # dict form = Modelbuilder.forward: both spellings of the batch, plus lifting and MPJPE on the device
     gt = torch.randn(frames, V, 17, 3, device="cuda").double()
-    metrics, out = m({"img": img, "KRT": P, "other_index": src, "points-3d": gt, "num_views": V}, is_train=False)
-    metrics2, out2 = m({"img": img, "KRT": P, "other_img": img[src], "other_KRT": P[src.cpu()], "num_views": V}, is_train=False)
+    _, metrics, out = m({"img": img, "KRT": P, "other_index": src, "points-3d": gt, "num_views": V}, is_train=False)
+    _, metrics2, out2 = m({"img": img, "KRT": P, "other_img": img[src], "other_KRT": P[src.cpu()], "num_views": V}, is_train=False)
     assert out["points-3d"].is_cuda and tuple(out["points-3d"].shape) == (frames, 17, 3) and "MPJPE" in metrics
     assert (out["batch_locs"] - out2["batch_locs"]).abs().max().item() <= 1e-2
     # training: the reference's loss entry, gradients reach the trunk and the layer
     m.train()
     loss, _ = m({"img": img, "KRT": P, "other_index": src, "heatmap": torch.rand(frames * V, 17, hs, hs, device="cuda"),
                  "visibility": torch.ones(frames * V, 17, 1, device="cuda"), "num_views": V}, is_train=True)
-    loss["stage_loss0"].backward()
+    loss["loss"].backward()
     assert m.reference.conv1.weight.grad is not None and m.reference.epipolar_sampler.z.weight.grad is not None
 
 
@@ -151,3 +151,69 @@ def test_lifting_on_device_matches_the_reference_linear_triangulation():
             _, _, vt = np.linalg.svd(np.array(A))
             want = vt[-1, :3] / vt[-1, 3]
             assert np.abs(got[f, k] - want).max() <= 1e-6 * max(1.0, np.abs(want).max()), (f, k)
+
+
+def test_model_equals_the_reference_modelbuilder_fixture():
+    """Row N1 pinned to reference CODE: tests/golden/model_r18.npz holds what the REAL reference `Modelbuilder`
+    (modeling/model.py:160-302, two backbone passes per pair, CPU) produced for 2 frames x 4 views of epipolarposeR-18 --
+    heat maps, detections, corr_pos, depth in eval mode; the loss and three gradient tensors of one training step.
+    `MultiViewPoseModel` with the same (name-derived) weights must reproduce them on the GPU, with the trunk run once per
+    view (`other_index`) and in the reference's own two-pass spelling (`other_img` / `other_KRT`)."""
+    import os
+    import sys
+
+    from conftest import GOLDEN_DIR, assert_corr_pos
+    from epipolar_transformers_amd import ops
+    from epipolar_transformers_amd.model import MultiViewPoseModel
+
+    sys.path.insert(0, GOLDEN_DIR)
+    from model_weights import deterministic_state_dict
+
+    d = np.load(os.path.join(GOLDEN_DIR, "model_r18.npz"))
+    frames, V, size, hs, K, J = [int(v) for v in d["meta"]]
+    cfg, _, _ = _cfg(**{"VIS.MULTIVIEW": False, "EPIPOLAR.SAMPLESIZE": K, "KEYPOINT.NUM_PTS": J})
+    m = MultiViewPoseModel(cfg)
+    m.reference.load_state_dict(deterministic_state_dict(m.reference.state_dict()))
+    m = m.cuda().eval()
+    cam = torch.from_numpy(d["cam"]).cuda()
+    m.reference.epipolar_sampler._cams.get = lambda *a, **k: cam       # the algebra the reference computed for the fixture
+    img = torch.from_numpy(d["img"]).cuda()
+    src = torch.from_numpy(d["src"]).cuda()
+    KRT = torch.from_numpy(d["KRT"])
+    batches = {"once per view": {"img": img, "KRT": KRT, "other_index": src, "num_views": V},
+               "two passes": {"img": img, "KRT": KRT, "other_img": img[src], "other_KRT": KRT[src.cpu()], "num_views": V}}
+    hscale = float(np.abs(d["heat_eval"]).max())
+    for name, batch in batches.items():
+        with torch.no_grad():
+            _, _, out = m(dict(batch), is_train=False)
+        heat = out["heatmaps"].cpu().numpy()
+        assert np.abs(heat - d["heat_eval"]).max() <= 2e-4 * hscale, (name, np.abs(heat - d["heat_eval"]).max(), hscale)
+        assert np.abs(out["depth"].cpu().numpy() - d["depth"]).max() <= 2e-5, name
+        locs = ops.sample_locs(m.reference.epipolar_sampler.layer_spec(), cam).cpu().numpy()
+        assert_corr_pos(locs, out["corr_pos"].cpu().numpy(), d["corr_pos"], out["depth"].cpu().numpy(), True, tie=5e-6)
+        assert np.abs(out["batch_scos"].cpu().numpy() - d["scores_eval"]).max() <= 2e-4 * hscale, name
+        # detections: equal to a hundredth of an image pixel, except where the heat map's arg-max has a proven tie
+        got, want = out["batch_locs"].cpu().numpy(), d["locs_eval"]
+        far = np.abs(got - want).max(-1) > 1e-2
+        for n, j in zip(*np.nonzero(far)):
+            hm = heat[n, j]
+            top = np.sort(hm.ravel())[-2:]
+            assert top[1] - top[0] <= 4e-4 * hscale, (name, n, j, got[n, j], want[n, j], top)
+        assert far.mean() <= 0.05, name
+    # one training step: loss and gradients (BN batch statistics: the two reference passes see the same eight images)
+    m.train()
+    for name, batch in batches.items():
+        m.zero_grad()
+        b = dict(batch, heatmap=torch.from_numpy(d["target"]).cuda(), visibility=torch.from_numpy(d["vis"]).cuda())
+        loss, _ = m(b, is_train=True)
+        assert abs(loss["loss"].item() - float(d["loss"][0])) <= 2e-5 * float(d["loss"][0]), (name, loss["loss"].item(), d["loss"])
+        loss["loss"].backward()
+        net = m.reference
+        for got, want in ((net.conv1.weight.grad, d["grad_conv1"]), (net.epipolar_sampler.z.weight.grad[:16], d["grad_z_rows"]),
+                          (net.final_layer.weight.grad, d["grad_final"])):
+            scale = float(np.abs(want).max())
+            assert np.abs(got.cpu().numpy() - want).max() <= 2e-3 * scale, (name, np.abs(got.cpu().numpy() - want).max(), scale)
+        norms = {k: p.grad.norm().item() for k, p in net.named_parameters() if p.grad is not None}
+        assert sorted(norms) == [str(k) for k in d["grad_keys"]]
+        for k, w in zip(d["grad_keys"], d["grad_norms"]):
+            assert abs(norms[str(k)] - float(w)) <= 5e-3 * max(float(w), 1e-6), (name, str(k), norms[str(k)], float(w))
