@@ -46,8 +46,12 @@ class JointsMSELoss(nn.Module):
 
 
 class MultiViewPoseModel(nn.Module):
-    def __init__(self, cfg=None):
+    def __init__(self, cfg=None, sharded=None):
+        """sharded: a `parallel.ViewShardExchange` -- this process then owns the images of ITS cameras only (one camera
+        per GPU at world size = views) and the source features come through the exchange (`forward_views_sharded`);
+        what the reference does with nn.DataParallel inside one process (model.py:44,246-247)."""
         super().__init__()
+        self.sharded = sharded
         self.cfg = cfg = cfg if cfg is not None else get_cfg()
         assert "epipolarpose" in cfg.BACKBONE.BODY, "MultiViewPoseModel is the multiview_keypoint task of Modelbuilder"
         self.reference = backbones.build_backbone(cfg)                     # model.py:34
@@ -71,6 +75,32 @@ class MultiViewPoseModel(nn.Module):
             return net(img, [feats[source_index], other_KRT, None, KRT, camera, other_camera, None])
         feature = net.trunk(img)                                            # once per view
         other = feature[source_index]
+        if not self.cfg.EPIPOLAR.OTHER_GRAD:
+            other = other.detach()
+        x, corr_pos, depth, sample_locs = net._fuse(feature, net.epipolar_sampler, other, KRT, other_KRT, camera, other_camera)
+        heatmap = net.final_layer(x)
+        locs, scos = backbones.find_peaks(heatmap, self.cfg.KEYPOINT.SIGMA, self.cfg.BACKBONE.DOWNSAMPLE)
+        return feature, [heatmap], locs, scos, corr_pos, depth, sample_locs, None
+
+    def forward_views_sharded(self, img: torch.Tensor, KRT: torch.Tensor, other_KRT: torch.Tensor, camera=None,
+                              other_camera=None, num_chunks: int = 1):
+        """The view-sharded partition as a model path, forward AND backward.  img (M,3,Hi,Wi): the images
+        of this rank's cameras, camera-major (all frames of camera a, then of camera b, ..: `ViewShardExchange`'s pair
+        order); KRT / other_KRT (M,3,4): their projection matrices and those of their source views (the ring neighbour,
+        owned by another rank).  The trunk runs on the own images only; the source feature maps arrive through ONE
+        all-gather (`parallel.sharded_sources`, channels-last memory as the trunk leaves it), its backward returns
+        d(source maps) to their owners with ONE all-to-all; the weight gradients of the shared network are summed by the
+        caller (`parallel.allreduce_gradients` or DDP).  Returns the backbone's 8-tuple."""
+        from .parallel import sharded_sources
+
+        if self.sharded is None:
+            raise RuntimeError("MultiViewPoseModel was built without a ViewShardExchange (sharded=...)")
+        if self.cfg.EPIPOLAR.MERGE != "late" or self.backbone is not self.reference:
+            raise NotImplementedError("the view-sharded path covers MERGE late with SHARE_WEIGHTS (every configs/epipolar/*.yaml)")
+        net = self.reference
+        feature = net.trunk(img)                                            # own cameras only
+        nhwc = feature.permute(0, 2, 3, 1).contiguous()                     # (a view when the trunk ran channels_last)
+        other = sharded_sources(nhwc, self.sharded, num_chunks).permute(0, 3, 1, 2)
         if not self.cfg.EPIPOLAR.OTHER_GRAD:
             other = other.detach()
         x, corr_pos, depth, sample_locs = net._fuse(feature, net.epipolar_sampler, other, KRT, other_KRT, camera, other_camera)
@@ -135,7 +165,10 @@ class MultiViewPoseModel(nn.Module):
                 batch_locs, batch_scos = self.forward_multitest(img, KRT, views)
             heat = corr_pos = depths = None
         else:
-            if "other_index" in inputs:
+            if self.sharded is not None and "other_img" not in inputs and "other_index" not in inputs:
+                res = self.forward_views_sharded(img, KRT, inputs["other_KRT"].to(torch.float32), camera, other_camera,
+                                                 int(inputs.get("exchange_chunks", 1)))
+            elif "other_index" in inputs:
                 res = self.forward_views(img, KRT, inputs["other_index"], camera, other_camera)
             else:
                 with torch.set_grad_enabled(torch.is_grad_enabled() and bool(cfg.EPIPOLAR.OTHER_GRAD)):

@@ -162,6 +162,80 @@ class ViewShardExchange:
 
 
 # ---------------------------------------------------------------------------------------------------------------
+# The exchange as a differentiable step: what replaces the reference's nn.DataParallel scatter / gather of
+# `other_features` (modeling/model.py:44,246-247) when the views are sharded one camera per GPU
+# ---------------------------------------------------------------------------------------------------------------
+class _ShardedSources(torch.autograd.Function):
+    """own maps (this rank's cameras, camera-major) -> the source maps of this rank's pairs.  Forward: ONE all-gather
+    over the view group (`gather_sources`); backward: ONE all-to-all that returns d(source maps) to the ranks that own
+    those maps (`scatter_source_grads`: a permutation, every map is the source of exactly one reference camera)."""
+
+    @staticmethod
+    def forward(ctx, own_maps, exchange):
+        ctx.exchange = exchange
+        return exchange.gather_sources(own_maps.contiguous()).clone()
+
+    @staticmethod
+    def backward(ctx, grad):
+        return ctx.exchange.scatter_source_grads(grad.contiguous()), None
+
+
+def sharded_sources(own_maps: torch.Tensor, exchange: "ViewShardExchange", num_chunks: int = 1) -> torch.Tensor:
+    """Differentiable `gather_sources`: (len(my_cams) * frames, ...) own maps -> same shape, the source map of every
+    pair of this rank.  num_chunks > 1 splits the frames of every camera into ranges and exchanges range by range
+    (each range its own collective in the forward and in the backward), so that on the GPUs the fused kernel of
+    range i can run while range i + 1 is on the links."""
+    ncam = len(exchange.my_cams)
+    f = own_maps.shape[0] // ncam
+    num_chunks = max(1, min(int(num_chunks), f))
+    if num_chunks == 1:
+        return _ShardedSources.apply(own_maps, exchange)
+    per_cam = own_maps.reshape((ncam, f) + tuple(own_maps.shape[1:]))
+    bounds = [(i * f) // num_chunks for i in range(num_chunks + 1)]
+    parts = []
+    for lo, hi in zip(bounds[:-1], bounds[1:]):
+        chunk = per_cam[:, lo:hi].reshape((ncam * (hi - lo),) + tuple(own_maps.shape[1:]))
+        parts.append(_ShardedSources.apply(chunk, exchange).reshape((ncam, hi - lo) + tuple(own_maps.shape[1:])))
+    return torch.cat(parts, 1).reshape(own_maps.shape)
+
+
+def allreduce_gradients(module: torch.nn.Module, group=None, bucket_bytes: int = 64 << 20, average: bool = False):
+    """Sum (or average) the parameter gradients of `module` over the process group in flat buckets -- the weight-gradient
+    all-reduce of the shared network (EPIPOLAR.SHARE_WEIGHTS) that closes a sharded training step.  (torch's
+    DistributedDataParallel does the same, overlapped with the backward; this is the explicit form for loops that
+    scale the loss themselves.)  Parameters without a gradient on this rank contribute zeros."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return
+    params = [p for p in module.parameters() if p.requires_grad]
+    world = dist.get_world_size(group)
+    bucket, size = [], 0
+
+    def flush():
+        nonlocal bucket, size
+        if not bucket:
+            return
+        flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in bucket])
+        dist.all_reduce(flat, group=group)
+        if average:
+            flat /= world
+        off = 0
+        for p in bucket:
+            n = p.numel()
+            if p.grad is None:
+                p.grad = torch.empty_like(p)
+            p.grad.copy_(flat[off:off + n].view_as(p))
+            off += n
+        bucket, size = [], 0
+
+    for p in params:
+        bucket.append(p)
+        size += p.numel() * p.element_size()
+        if size >= bucket_bytes:
+            flush()
+    flush()
+
+
+# ---------------------------------------------------------------------------------------------------------------
 # Cross-rank coupling of the layer in TRAINING: the batch statistics of the z-epilogue's BN
 # ---------------------------------------------------------------------------------------------------------------
 class _SyncBNFunction(torch.autograd.Function):
