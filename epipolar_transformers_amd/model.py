@@ -35,14 +35,21 @@ def ring_sources(num_frames: int, num_views: int, device=None) -> torch.Tensor:
 
 
 class JointsMSELoss(nn.Module):
-    """modeling/metrics/metrics2d.py JointsMSELoss: per-joint MSE of visibility-weighted heat maps, 0.5 * mean."""
+    """modeling/metrics/metrics2d.py:18-41 JointsMSELoss: per joint the mean squared error of the visibility-weighted
+    heat maps (nn.MSELoss(reduction='mean') over batch x pixels), summed over the joints and -- unless
+    cfg.KEYPOINT.LOSS_PER_JOINT -- divided by their number.  (No factor 1/2: pinned by tests/golden/model_r18.npz.)"""
+
+    def __init__(self, per_joint: bool = False):
+        super().__init__()
+        self.per_joint = per_joint
 
     def forward(self, output, target, target_weight):
         n, j = output.shape[:2]
         pred = output.reshape(n, j, -1)
         gt = target.reshape(n, j, -1)
         w = target_weight.reshape(n, j, 1)
-        return 0.5 * ((pred * w - gt * w) ** 2).mean(dim=(0, 2)).sum() / j
+        loss = ((pred * w - gt * w) ** 2).mean(dim=(0, 2)).sum()
+        return loss if self.per_joint else loss / j
 
 
 class MultiViewPoseModel(nn.Module):
@@ -60,7 +67,7 @@ class MultiViewPoseModel(nn.Module):
             from .parallel import convert_sync_batchnorm
 
             convert_sync_batchnorm(self)
-        self.criterion = JointsMSELoss()
+        self.criterion = JointsMSELoss(bool(getattr(cfg.KEYPOINT, "LOSS_PER_JOINT", False)))
 
     # ------------------------------------------------------------------------------------------ N1
     def forward_views(self, img: torch.Tensor, KRT: torch.Tensor, source_index: torch.Tensor,
