@@ -105,6 +105,21 @@ class Epipolar(nn.Module):
                 not any(k in e.PARAMETERIZED for k in ("theta", "phi", "g")))
 
     def _attend_general(self, feat1, feat2, P1, P2, camera=None, other_camera=None, ref1=None, ref2=None):
+        """`_attend_general_chunk` over ranges of pairs, so that the sampled K x C x H x W tensors (what the reference
+        materialises per PAIR, epipolar.py:199-213) never exceed ~2 GB at once however large the batch is
+        (keypoint_h36m_param.yaml at 32 frames x 4 views would otherwise hold 17 GB per sampled map)."""
+        N, C, H, W = feat2.shape
+        per_pair = 2 * self.sample_size * max(C, feat1.shape[1]) * H * W * 4 * (2 if torch.is_grad_enabled() else 1)
+        step = max(1, int(amd_knob(self.cfg, "GENERAL_MODE_BYTES", 2 << 30)) // per_pair)
+        if step >= N:
+            return self._attend_general_chunk(feat1, feat2, P1, P2, camera, other_camera, ref1, ref2)
+        sl = lambda t, a, b: None if t is None else t[a:b]
+        parts = [self._attend_general_chunk(feat1[a:a + step], feat2[a:a + step], P1[a:a + step], P2[a:a + step],
+                                            sl(camera, a, a + step), sl(other_camera, a, a + step), sl(ref1, a, a + step),
+                                            sl(ref2, a, a + step)) for a in range(0, N, step)]
+        return tuple(torch.cat([p[i] for p in parts]) for i in range(3))
+
+    def _attend_general_chunk(self, feat1, feat2, P1, P2, camera=None, other_camera=None, ref1=None, ref2=None):
         """The operator's non-headline branches, restated op for op from epipolar.py:131-247 and
         epipolar_similarity (:272-321) as batched GPU torch ops (autograd included).  Returns (out, attn, corr_pos)
         like `attend`; `out` is what the reference stacks at :247 (before z)."""
@@ -177,6 +192,48 @@ class Epipolar(nn.Module):
         else:
             out = (s2 * sim.unsqueeze(2)).sum(1)                              # :243
         return out, sim, corr_pos
+
+    # ------------------------------------------------------------ debug geometry
+    def _debug_geometry(self, cam: torch.Tensor):
+        """The intermediates the reference returns with debug=True (epipolar.py:350-407, 416-417): rectangle intersections
+        (N,HW,4,2), their validity mask (N,HW,4), the two chosen ones (N,HW,2,2), start (N,HW,2) and vec (1,N,HW,2), from the
+        per-pair algebra `cam` (N,27).  Batched torch ops on the device -- visualisation aids: the sample locations
+        themselves always come from the HIP geometry kernel (bit-equal to the reference), these are consistent with them
+        to float32 rounding.  More than two valid intersections (a line through a corner; the reference raises there):
+        the first two in edge order, as the kernels do."""
+        spec = self.layer_spec()
+        xs, ys, _ = spec.constants(cam.device)
+        N, H, W = cam.shape[0], self.feat_h, self.feat_w
+        gx, gy = xs.view(1, W).expand(H, W).reshape(-1), ys.view(H, 1).expand(H, W).reshape(-1)
+        grid = torch.stack([gx, gy, torch.ones_like(gx)])                       # (3,HW)   epipolar.py:40-44
+        X = cam[:, :12].view(N, 4, 3) @ grid                                    # :338
+        x2 = cam[:, 12:24].view(N, 3, 4) @ X                                    # :340
+        x2 = x2 / x2[:, 2:3]                                                    # :342
+        e2 = cam[:, 24:27].view(N, 3, 1)
+        l2 = torch.cross(e2.expand_as(x2), x2, dim=1).transpose(1, 2)           # (N,HW,3)  :350-352
+        xmin, xmax, ymin, ymax, eps = float(xs[0]), float(xs[-1]), float(ys[0]), float(ys[-1]), self.epsilon
+        den1 = torch.sign(l2[..., 1]) * l2[..., 1].abs().clamp_min(eps)
+        den0 = torch.sign(l2[..., 0]) * l2[..., 0].abs().clamp_min(eps)
+        by1 = -(xmin * l2[..., 0] + l2[..., 2]) / den1                          # :369-373
+        by2 = -(xmax * l2[..., 0] + l2[..., 2]) / den1
+        bx0 = -(ymin * l2[..., 1] + l2[..., 2]) / den0
+        bx3 = -(ymax * l2[..., 1] + l2[..., 2]) / den0
+        inter = torch.stack((bx0, by1, by2, bx3), -1).view(N, H * W, 4, 1).repeat(1, 1, 1, 2)   # :375-386
+        inter[..., 0, 1], inter[..., 1, 0], inter[..., 2, 0], inter[..., 3, 1] = ymin, xmin, xmax, ymax
+        mask = torch.stack(((bx0 >= xmin + eps) & (bx0 < xmax - eps), (by1 > ymin + eps) & (by1 <= ymax - eps),
+                            (by2 >= ymin + eps) & (by2 < ymax - eps), (bx3 > xmin + eps) & (bx3 <= xmax - eps)), -1)   # :388-393
+        few = mask.sum(-1) < 2
+        mask = mask & ~few.unsqueeze(-1)                                        # :397
+        rank = mask.cumsum(-1)
+        first = (mask & (rank == 1)).float().argmax(-1)                         # first two valid in edge order
+        second = (mask & (rank == 2)).float().argmax(-1)
+        pick = lambda idx: torch.gather(inter, 2, idx.view(N, H * W, 1, 1).expand(-1, -1, 1, 2)).squeeze(2)
+        valid = torch.stack((pick(first), pick(second)), 2)                     # (N,HW,2,2)  :402
+        out = inter.new_tensor([xmin - 10000.0, ymin - 10000.0])
+        valid = torch.where(few.view(N, H * W, 1, 1), out.view(1, 1, 1, 2), valid)   # :403
+        start = valid[..., 0, :]
+        vec = (valid[..., 1, :] - start).view(1, N, H * W, 2)                   # :405-407
+        return inter, mask, valid, start, vec
 
     # --------------------------------------------------------------- forward
     # Optional (P_ref_cpu, P_src_cpu) of the batch the CALLING THREAD is about to run, handed over by a launcher that
@@ -257,11 +314,6 @@ class Epipolar(nn.Module):
         feat1, feat2: N x C x H x W ; P1, P2: N x 3 x 4
         returns (finalout, corr_pos[N,H,W,2], depth[N,K,H,W], sample_locs | None)."""
         self._check_mode(depth, ref1, ref2)
-        if self.debug:
-            # the reference's debug mode returns a 9-tuple with the intermediate geometry (epipolar.py:264-265);
-            # the fused kernels never materialise it
-            raise NotImplementedError("Epipolar(debug=True): the 9-tuple of geometry intermediates is not produced by "
-                                      "the fused path; use VIS.EPIPOLAR_LINE for sample_locs")
         fused = self._fused_mode(ref1, ref2)
         if fused:
             out, attn, corr_pos = self.attend(feat1, feat2, P1, P2)
@@ -278,6 +330,10 @@ class Epipolar(nn.Module):
         else:
             finalout, _ = self._epilogue_torch(out)
         sample_locs = None
+        if self.debug:
+            # epipolar.py:264-265: the 9-tuple of the visualisers -- sample_locs untransposed (K,N,H,W,2) + the geometry
+            cam = self._cam(P1, P2, feat1.device)
+            return (finalout, corr_pos, attn, ops.sample_locs(self.layer_spec(), cam)) + self._debug_geometry(cam)
         if self.cfg.VIS.EPIPOLAR_LINE:
             cam = self._cam(P1, P2, feat1.device)
             sample_locs = ops.sample_locs(self.layer_spec(), cam).transpose(0, 1)   # (K,N,H,W,2) -> epipolar.py:267

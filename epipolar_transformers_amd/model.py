@@ -133,8 +133,16 @@ class MultiViewPoseModel(nn.Module):
             src_idx.append(base.roll(-shift, 1).reshape(-1))
         ref_idx, src_idx = torch.cat(ref_idx), torch.cat(src_idx)
         Kc = KRT.to("cpu")
+        camera = other_camera = None
+        if self.cfg.EPIPOLAR.PRIOR or self.cfg.EPIPOLAR.SIMILARITY == "prior":
+            # the learned per-camera-pair tables (epipolar.py:73-80,288-301) are keyed by the camera ids of the data set:
+            # view v of a frame-major batch is cfg.DATASETS.CAMERAS[v] (multiview_h36m.py:225-252)
+            ids = list(self.cfg.DATASETS.CAMERAS)
+            assert len(ids) >= num_views, "EPIPOLAR.PRIOR needs DATASETS.CAMERAS to name every view"
+            camera = [ids[int(i) % num_views] for i in ref_idx.tolist()]
+            other_camera = [ids[int(i) % num_views] for i in src_idx.tolist()]
         x, _, _, _ = net._fuse(feature[ref_idx], net.epipolar_sampler, source[src_idx], Kc[ref_idx.cpu()], Kc[src_idx.cpu()],
-                               None, None)
+                               camera, other_camera)
         heat = net.final_layer(x)
         locs, scos = backbones.find_peaks(heat, self.cfg.KEYPOINT.SIGMA, self.cfg.BACKBONE.DOWNSAMPLE)
         locs = locs.view(num_views - 1, m, -1, 2)
