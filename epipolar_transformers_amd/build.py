@@ -140,7 +140,7 @@ def build_profile_library(defines=("-DET_WS_PROFILE=2",)) -> str:
 
 if __name__ == "__main__":
     if "--profile" in sys.argv:
-        print(build_profile_library(tuple(a for a in sys.argv[1:] if a.startswith("-D")) or ("-DET_WS_PROFILE=2",)))
+        print(build_profile_library(tuple(a for a in sys.argv[1:] if a.startswith(("-D", "-f", "-m"))) or ("-DET_WS_PROFILE=2",)))
     else:
         build_library(force=True, report="--report" in sys.argv)
         print(LIB)

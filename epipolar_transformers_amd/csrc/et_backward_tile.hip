@@ -80,7 +80,7 @@ int et_epipolar_backward_tiled_attn(const EtLayerDesc *desc, const float *xs, co
                         !(desc->variant & ET_VARIANT_TILE_CLASSIC);
     const int rows = !merged ? tile_rows(desc) : tile_rows(desc) == kTileRowsSmall ? kTileRowsMerged : kTileRowsMergedLarge;
     if (merged && tp.rows_cap > rows) tp.rows_cap = rows;
-    const size_t lds = (size_t)(bwd_tile_array_floats(rows) + rows + kTilePix + 20 + kTilePix * 4) * 4 +
+    const size_t lds = (size_t)(bwd_tile_array_floats(rows) + rows + kTilePix + 60 + kTilePix * 4) * 4 +
                        (size_t)tp.hw_words * 8 + ((kpl == 1 && !merged) ? (size_t)kTilePix * kWave * 8 : 0);
 #define ET_BTILE(KK, RR)                                                                                        \
     do {                                                                                                        \

@@ -57,6 +57,28 @@ __device__ __forceinline__ void split_f16x8(const float (&v)[8], f16x8 &hi, f16x
     lo = __builtin_bit_cast(f16x8, l);
 }
 
+// The split of eight values for the second GEMM's source rows, on the register pairs the loads and the lane trade leave them in
+// (v[i] = (row i of the even channel, row i of the odd channel)): the scale multiply stays packed on those pairs.
+// Paired any other way (e.g. rows i, i + 1 of one channel as a packed multiply) every k-step copies its freshly loaded
+// registers into the other arrangement right behind the loads -- i.e. waits for them.
+__device__ __forceinline__ void split_f16x8_pairs(const f32x2 (&v)[8], f16x8 &ehi, f16x8 &elo, f16x8 &ohi, f16x8 &olo)
+{
+    u32x4 eh, el, oh, ol;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        unsigned hh, ll;
+        split_f16_pair(v[2 * i][0], v[2 * i + 1][0], hh, ll);
+        eh[i] = hh;
+        el[i] = ll;
+        split_f16_pair(v[2 * i][1], v[2 * i + 1][1], hh, ll);
+        oh[i] = hh;
+        ol[i] = ll;
+    }
+    ehi = __builtin_bit_cast(f16x8, eh);
+    elo = __builtin_bit_cast(f16x8, el);
+    ohi = __builtin_bit_cast(f16x8, oh);
+    olo = __builtin_bit_cast(f16x8, ol);
+}
 // power of two that puts a magnitude mx into [2^10, 2^11) (fp16 keeps a factor 32 of head-room above it), and its
 // inverse; mx = 0 / denormal / huge are clamped to a finite pair
 __device__ __forceinline__ void pow2_scale_of(float mx, float &sc, float &inv)
