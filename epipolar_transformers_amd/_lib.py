@@ -31,7 +31,9 @@ ET_VARIANT_TILE_SPLIT = 32768
 ET_VARIANT_TILE_CLASSIC = 65536
 ET_VARIANT_WS_V2 = 131072
 ET_VARIANT_WS_SETPRIO = 262144
-ET_ABI_VERSION = 9
+ET_ABI_VERSION = 10
+ET_GENERAL_POOLING = 1
+ET_GENERAL_PRIOR_MUL = 2
 
 
 class EpipolarAmdError(RuntimeError):
@@ -60,6 +62,7 @@ _SIGNATURES = {
     "et_last_error": (ctypes.c_char_p, []),
     "et_sample_locs": (ctypes.c_int, [_D, _P, _P, _P, _P, _P, _P]),
     "et_epipolar_forward": (ctypes.c_int, [_D, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "et_epipolar_forward_general": (ctypes.c_int, [_D] + [_P] * 8 + [ctypes.c_int32] * 3 + [_P] * 4),
     "et_epipolar_forward_workspace_bytes": (ctypes.c_size_t, [_D]),
     "et_epipolar_forward_workspace_stats_offset": (ctypes.c_size_t, [_D]),
     "et_epipolar_forward_workspace_error_offset": (ctypes.c_size_t, [_D]),

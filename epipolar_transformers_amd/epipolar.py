@@ -108,6 +108,8 @@ class Epipolar(nn.Module):
         """`_attend_general_chunk` over ranges of pairs, so that the sampled K x C x H x W tensors (what the reference
         materialises per PAIR, epipolar.py:199-213) never exceed ~2 GB at once however large the batch is
         (keypoint_h36m_param.yaml at 32 frames x 4 views would otherwise hold 17 GB per sampled map)."""
+        if self._general_kernel_applies(feat1, feat2, ref1, ref2):
+            return self._attend_general_hip(feat1, feat2, P1, P2, camera, other_camera)
         N, C, H, W = feat2.shape
         per_pair = 2 * self.sample_size * max(C, feat1.shape[1]) * H * W * 4 * (2 if torch.is_grad_enabled() else 1)
         step = max(1, int(amd_knob(self.cfg, "GENERAL_MODE_BYTES", 2 << 30)) // per_pair)
@@ -118,6 +120,44 @@ class Epipolar(nn.Module):
                                             sl(camera, a, a + step), sl(other_camera, a, a + step), sl(ref1, a, a + step),
                                             sl(ref2, a, a + step)) for a in range(0, N, step)]
         return tuple(torch.cat([p[i] for p in parts]) for i in range(3))
+
+    def _general_kernel_applies(self, feat1, feat2, ref1=None, ref2=None) -> bool:
+        """True when `et_epipolar_forward_general` computes this call: ATTENTION avg over a dot-product similarity of
+        feature maps (theta / phi / g, BOTTLENECK, POOLING, PRIOR / PRIORMUL in any combination), and nothing asks for a
+        gradient -- the kernel is forward only, training of these modes takes the chunked torch restatement below."""
+        e = self.cfg.EPIPOLAR
+        if not (e.ATTENTION == "avg" and e.SIMILARITY == "dot" and e.FIND_CORR == "feature" and ref1 is None and ref2 is None):
+            return False
+        if not bool(amd_knob(self.cfg, "GENERAL_KERNEL", True)) or not feat1.is_cuda:
+            return False
+        if e.POOLING and self.sample_size % 2:
+            return False
+        if torch.is_grad_enabled():
+            params = [q for k in ("theta", "phi", "g") if k in e.PARAMETERIZED for q in getattr(self, k).parameters()]
+            if e.PRIOR:
+                params += list(self.prior.values())
+            if feat1.requires_grad or feat2.requires_grad or any(q.requires_grad for q in params):
+                return False
+        c_sim = feat1.shape[1] // (e.BOTTLENECK if "theta" in e.PARAMETERIZED else 1)
+        return c_sim <= 512
+
+    def _attend_general_hip(self, feat1, feat2, P1, P2, camera=None, other_camera=None):
+        """The parameterised / pooled / prior branches through ONE HIP kernel (ops.forward_general_nhwc): the 1x1
+        convolutions act on the maps (epipolar.py:138-153: torch / MIOpen GEMMs), the kernel samples, pools, masks,
+        soft-maxes and sums without materialising a K x C x H x W tensor."""
+        e = self.cfg.EPIPOLAR
+        with torch.no_grad():
+            q = self.theta(feat1) if "theta" in e.PARAMETERIZED else feat1                  # :144-145
+            m1 = self.phi(feat2) if "phi" in e.PARAMETERIZED else feat2                     # :142-143
+            m2 = self.g(feat2) if "g" in e.PARAMETERIZED else feat2                         # :152-153
+            prior = None
+            if e.PRIOR:                                                                     # :288-289, :300-301
+                prior = torch.stack([self.prior[(int(a), int(b))].to(q) for a, b in zip(camera, other_camera)]).contiguous()
+            cam = self._cam(P1, P2, feat2.device)
+            out, attn, corr_pos = ops.forward_general_nhwc(self.layer_spec(), ops.to_nhwc(q), ops.to_nhwc(m1), ops.to_nhwc(m2),
+                                                           cam, prior=prior, pooling=bool(e.POOLING),
+                                                           prior_mul=bool(e.PRIOR and e.PRIORMUL))
+        return out.permute(0, 3, 1, 2), attn, corr_pos
 
     def _attend_general_chunk(self, feat1, feat2, P1, P2, camera=None, other_camera=None, ref1=None, ref2=None):
         """The operator's non-headline branches, restated op for op from epipolar.py:131-247 and

@@ -120,6 +120,41 @@ def sample_locs(spec: LayerSpec, cam: torch.Tensor) -> torch.Tensor:
     return out
 
 
+def forward_general_nhwc(spec: LayerSpec, q: torch.Tensor, map_sim: torch.Tensor, map_val: torch.Tensor, cam: torch.Tensor,
+                         prior: torch.Tensor = None, pooling=False, prior_mul=False, want_attn=True, want_corr=True):
+    """The operator's parameterised / pooled / prior branches as ONE kernel (et_epipolar_forward_general; forward only).
+    q, map_sim: (N,H,W,Cs); map_val: (N,H,W,Cv), channels last, contiguous; prior: (N,K',H,W) or None, K' = K/2 with
+    `pooling` (epipolar.py:200-202), else K.  Returns out (N,H,W,Cv), attn (N,K',H,W)|None, corr_pos (N,H,W,2)|None."""
+    for t, nm in ((q, "q"), (map_sim, "map_sim"), (map_val, "map_val"), (cam, "cam")):
+        _require_gpu(t, nm)
+    n, h, w, cs = q.shape
+    cv = map_val.shape[-1]
+    if (h, w) != (spec.H, spec.W) or map_sim.shape != q.shape or map_val.shape[:3] != q.shape[:3]:
+        raise ValueError("maps %s / %s / %s do not match the layer's %dx%d" %
+                         (tuple(q.shape), tuple(map_sim.shape), tuple(map_val.shape), spec.H, spec.W))
+    if cam.shape != (n, _lib.ET_CAM_STRIDE) or not cam.is_contiguous():
+        raise ValueError("cam must be a contiguous (N,%d) tensor" % _lib.ET_CAM_STRIDE)
+    if not (q.is_contiguous() and map_sim.is_contiguous() and map_val.is_contiguous()):
+        raise ValueError("q / map_sim / map_val must be contiguous (N,H,W,C) tensors")
+    ks = spec.K // 2 if pooling else spec.K
+    if prior is not None:
+        _require_gpu(prior, "prior")
+        if tuple(prior.shape) != (n, ks, h, w) or not prior.is_contiguous():
+            raise ValueError("prior must be (N,K',H,W) = %s, got %s" % ((n, ks, h, w), tuple(prior.shape)))
+    xs, ys, steps = spec.constants(q.device)
+    out = torch.empty((n, h, w, cv), dtype=torch.float32, device=q.device)
+    attn = torch.empty((n, ks, h, w), dtype=torch.float32, device=q.device) if want_attn else None
+    corr = torch.empty((n, h, w, 2), dtype=torch.float32, device=q.device) if want_corr else None
+    flags = (_lib.ET_GENERAL_POOLING if pooling else 0) | (_lib.ET_GENERAL_PRIOR_MUL if prior_mul else 0)
+    d = spec.desc(n, 4)
+    with torch.cuda.device(q.device):
+        _lib.check(_lib.load().et_epipolar_forward_general(
+            ctypes.byref(d), _ptr(xs), _ptr(ys), _ptr(steps), _ptr(cam), _ptr(q), _ptr(map_sim), _ptr(map_val),
+            _ptr(prior) if prior is not None else None, cs, cv, flags, _ptr(out), _ptr(attn) if want_attn else None,
+            _ptr(corr) if want_corr else None, _stream(q)), "et_epipolar_forward_general")
+    return out, attn, corr
+
+
 _TILE_BITS = (_lib.ET_VARIANT_TILE_SPLIT | _lib.ET_VARIANT_TILE_CLASSIC | _lib.ET_VARIANT_WS_V2 |
               _lib.ET_VARIANT_WS_SETPRIO)      # variant bits that tune the tile path instead of leaving it
 

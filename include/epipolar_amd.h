@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define ET_ABI_VERSION 9
+#define ET_ABI_VERSION 10
 
 /* Static description of one layer call: the cfg keys the reference reads in
  * Epipolar.__init__ (epipolar.py:12-54) and at call time (epipolar.py:303-311,
@@ -149,6 +149,29 @@ int et_epipolar_forward_tiled(const EtLayerDesc *desc, const float *xs, const fl
                               const float *cam, const float *feat_ref, const float *feat_src, float *out,
                               float *attn, float *corr_pos, const float *res_bias, float *res_base,
                               void *workspace, size_t workspace_bytes, void *stream);
+
+/* The operator's parameterised / pooled / prior branches as one kernel, forward only.
+ * The reference applies its optional 1x1 convolutions to the maps BEFORE sampling (epipolar.py:138-153), so these
+ * branches are the headline operator over three tensors instead of two:
+ *   q        : (N,H,W,c_sim)  feat1 or theta(feat1)                          (epipolar.py:144-145)
+ *   map_sim  : (N,H,W,c_sim)  feat2 or phi(feat2): sampled for the similarity (epipolar.py:138-143, :199)
+ *   map_val  : (N,H,W,c_val)  feat2 or g(feat2):   sampled for the output     (epipolar.py:147-153, :210)
+ *   prior    nullable : (N,K',H,W)  EPIPOLAR.PRIOR: the (camera, other camera) prior of every pair, added to the masked
+ *                        similarity (epipolar.py:300-301) or, with ET_GENERAL_PRIOR_MUL, multiplied onto the soft-max
+ *                        output (epipolar.py:308-309)
+ *   flags    : ET_GENERAL_POOLING -- EPIPOLAR.POOLING (epipolar.py:200-202, 211-213): per-channel maximum of samples
+ *              k and k + K/2 of both sampled maps; K' = K / 2 similarities per pixel (K even).  Otherwise K' = K.
+ *   out      : (N,H,W,c_val)  sum_k' attn_k' * (pooled) sample_k' of map_val   (epipolar.py:243)
+ *   attn     nullable : (N,K',H,W);  corr_pos nullable : (N,H,W,2), the location of sample arg-max_k' attn of the
+ *              unpooled list (epipolar.py:237-242).
+ * ATTENTION avg, SIMILARITY dot, FIND_CORR feature; soft-max on or off as `desc` says; desc->C is ignored
+ * (c_sim <= 512, c_val <= 4096, any positive value).  Nothing of size K x C x H x W is materialised. */
+#define ET_GENERAL_POOLING 1
+#define ET_GENERAL_PRIOR_MUL 2
+int et_epipolar_forward_general(const EtLayerDesc *desc, const float *xs, const float *ys, const float *steps,
+                                const float *cam, const float *q, const float *map_sim, const float *map_val,
+                                const float *prior, int c_sim, int c_val, int flags, float *out, float *attn,
+                                float *corr_pos, void *stream);
 
 /* Backward of et_epipolar_forward w.r.t. both feature maps (sample locations
  * carry no gradient, epipolar.py:178-183).  Everything is recomputed from the

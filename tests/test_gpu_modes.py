@@ -151,3 +151,98 @@ def test_debug_mode_returns_the_reference_nine_tuple():
     pix = (pos + 0.5 - 4 / 2.0) / 4                                       # coord2pix (multiview.py:163), resize factors 1
     norm = -1 + 2 * pix / (H - 1)                                         # normalize, USE_CORRECT_NORMALIZE (multiview.py:30-32)
     assert (norm.view(K, N, H, H, 2) - locs).abs().max().item() <= 2e-4
+
+
+# ---- the parameterised / pooled / prior branches as ONE HIP kernel (et_epipolar_forward_general, forward only) ----------
+GENERAL_KERNEL_MODES = [m for m in MODES if m.startswith(("param_pool", "prior_add", "prior_mul"))]
+
+
+@pytest.mark.parametrize("name", GENERAL_KERNEL_MODES)
+def test_general_kernel_vs_reference(name):
+    """No gradient requested -> the module takes `et_epipolar_forward_general`; its outputs against the REAL reference's
+    (theta / phi / g with BOTTLENECK 2 + POOLING; PRIOR added; PRIOR multiplied)."""
+    d = np.load(os.path.join(GOLDEN_DIR, "modes", name + ".npz"))
+    mod = _module(d)
+    dev = lambda k: torch.from_numpy(d[k]).cuda()
+    f1, f2 = dev("feat1"), dev("feat2")
+    with torch.no_grad():
+        assert mod._general_kernel_applies(f1, f2)
+    called = []
+    from epipolar_transformers_amd import ops
+    real = ops.forward_general_nhwc
+    ops.forward_general_nhwc = lambda *a, **k: (called.append(1), real(*a, **k))[1]
+    try:
+        with torch.no_grad():
+            fin, corr, depth, _ = mod(f1, f2, torch.from_numpy(d["P1"]), torch.from_numpy(d["P2"]),
+                                      camera=torch.from_numpy(d["camera"]), other_camera=torch.from_numpy(d["other_camera"]))
+    finally:
+        ops.forward_general_nhwc = real
+    assert called, "the HIP general kernel did not run"
+    assert tuple(fin.shape) == d["finalout"].shape and tuple(depth.shape) == d["depth"].shape
+    locs = ops.sample_locs(mod.layer_spec(), torch.from_numpy(d["cam"]).cuda()).cpu().numpy()
+    depth_np = depth.cpu().numpy()
+    assert_corr_pos(locs, corr.cpu().numpy(), d["corr_pos"], depth_np, True, tie=2e-6, max_frac=2e-2)
+    assert np.abs(depth_np - d["depth"]).max() <= 1e-5 * max(1.0, float(np.abs(d["depth"]).max()))
+    assert np.abs(fin.cpu().numpy() - d["finalout"]).max() <= 1e-4 * max(1.0, float(np.abs(d["finalout"]).max()))
+
+
+@pytest.mark.parametrize("case", [
+    dict(H=64, C=256, K=64, N=4, bottleneck=2, pooling=True, prior=False, softmax=True),     # keypoint_h36m_param.yaml's head
+    dict(H=24, C=64, K=33, N=3, bottleneck=1, pooling=False, prior=True, softmax=True),      # ragged K, prior added
+    dict(H=16, C=32, K=130, N=2, bottleneck=4, pooling=True, prior=True, priormul=True, softmax=True),   # K' = 65 > one wave
+    dict(H=16, C=16, K=12, N=2, bottleneck=1, pooling=True, prior=False, softmax=False),     # soft-max off: sim / K'
+])
+def test_general_kernel_vs_torch_restatement(case):
+    """The HIP kernel against the chunked torch restatement of the same branches (itself pinned to the reference fixtures
+    by test_mode_vs_reference) at shapes the fixtures do not reach."""
+    from epipolar_transformers_amd import default_cfg, synthetic as syn
+    from epipolar_transformers_amd.epipolar import Epipolar
+
+    H, C, K, N = case["H"], case["C"], case["K"], case["N"]
+    par = ("z",) + (("theta", "phi", "g") if case["bottleneck"] > 1 else ("phi",))
+    cfg = default_cfg()
+    cfg.merge_from_list(["KEYPOINT.HEATMAP_SIZE", (H, H), "KEYPOINT.NFEATS", C, "EPIPOLAR.SAMPLESIZE", K,
+                         "DATASETS.IMAGE_SIZE", (4 * H, 4 * H), "EPIPOLAR.USE_CORRECT_NORMALIZE", True,
+                         "EPIPOLAR.ATTENTION", "avg", "EPIPOLAR.PARAMETERIZED", par, "EPIPOLAR.BOTTLENECK", case["bottleneck"],
+                         "EPIPOLAR.ZRESIDUAL", case["bottleneck"] == 1, "EPIPOLAR.POOLING", case["pooling"],
+                         "EPIPOLAR.PRIOR", case["prior"], "EPIPOLAR.PRIORMUL", bool(case.get("priormul")),
+                         "EPIPOLAR.SOFTMAX_ENABLED", case["softmax"], "DATASETS.CAMERAS", (0, 1, 2, 3)])
+    torch.manual_seed(7)
+    mod = Epipolar(cfg=cfg).cuda().eval()
+    with torch.no_grad():
+        for nm in ("theta", "phi", "g"):
+            if nm in par:
+                getattr(mod, nm).weight.normal_(0, 0.3)
+                getattr(mod, nm).bias.normal_(0, 0.3)
+        if case["prior"]:
+            mod.prior = {k: torch.nn.Parameter(torch.rand(K // 2 if case["pooling"] else K, H, H, device="cuda") * 0.5)
+                         for k in mod.prior}
+    P1, P2 = syn.make_pairs((N + 3) // 4, 4, 4 * H, seed=11, jitter=(0.05, 4.0))
+    P1, P2 = P1[:N], P2[:N]
+    f1, f2 = syn.make_features(N, C, H, H, seed=12)
+    f1, f2 = f1.cuda(), f2.cuda()
+    f2[:, :, 2, 3] = 0.0                                    # an all-zero source pixel: exact-zero taps
+    f1[:, :, 5, 5] = 0.0                                    # an all-zero reference pixel (dot == 0 -> masked everywhere unless biased)
+    cams = torch.arange(N) % 4, (torch.arange(N) + 1) % 4
+    with torch.no_grad():
+        assert mod._general_kernel_applies(f1, f2)
+        out_h, attn_h, corr_h = mod._attend_general(f1, f2, P1, P2, cams[0], cams[1])
+        out_t, attn_t, corr_t = mod._attend_general_chunk(f1, f2, P1, P2, cams[0], cams[1])
+    assert attn_h.shape == attn_t.shape and out_h.shape == out_t.shape
+    assert (attn_h - attn_t).abs().max().item() <= 1e-5 * max(1.0, attn_t.abs().max().item())
+    assert (out_h - out_t).abs().max().item() <= 1e-4 * max(1.0, out_t.abs().max().item())
+    from epipolar_transformers_amd import ops
+    locs = ops.sample_locs(mod.layer_spec(), mod._cam(P1, P2, f1.device)).cpu().numpy()
+    assert_corr_pos(locs, corr_h.cpu().numpy(), corr_t.cpu().numpy(), attn_h.cpu().numpy(), True, tie=2e-6, max_frac=2e-2)
+
+
+def test_general_kernel_is_not_taken_when_a_gradient_is_requested():
+    d = np.load(os.path.join(GOLDEN_DIR, "modes", "param_pool_c16_k16.npz"))
+    mod = _module(d)
+    f1, f2 = torch.from_numpy(d["feat1"]).cuda(), torch.from_numpy(d["feat2"]).cuda()
+    assert not mod._general_kernel_applies(f1, f2)                     # parameters of theta / phi / g require a gradient
+    with torch.no_grad():
+        assert mod._general_kernel_applies(f1, f2)
+    for q in mod.parameters():
+        q.requires_grad_(False)
+    assert mod._general_kernel_applies(f1, f2) and not mod._general_kernel_applies(f1.requires_grad_(True), f2)
