@@ -63,6 +63,7 @@ _SIGNATURES = {
     "et_sample_locs": (ctypes.c_int, [_D, _P, _P, _P, _P, _P, _P]),
     "et_epipolar_forward": (ctypes.c_int, [_D, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "et_epipolar_forward_general": (ctypes.c_int, [_D] + [_P] * 8 + [ctypes.c_int32] * 3 + [_P] * 4),
+    "et_epipolar_backward_general": (ctypes.c_int, [_D] + [_P] * 8 + [ctypes.c_int32] * 3 + [_P] * 4),
     "et_epipolar_forward_workspace_bytes": (ctypes.c_size_t, [_D]),
     "et_epipolar_forward_workspace_stats_offset": (ctypes.c_size_t, [_D]),
     "et_epipolar_forward_workspace_error_offset": (ctypes.c_size_t, [_D]),

@@ -15,8 +15,8 @@
 //   lanes <-> samples : `== 0 -> -1e10` mask, prior, soft-max (or / K'), first arg-max -> attn, corr_pos
 //   lanes <-> channels: out[c] = sum_k' attn[k'] * pooled sample of the value map
 // HBM/L2-bound gather like the per-pixel headline kernel (algorithmic bytes per pixel: K x 4 taps x (Cs + Cv) x 4 B);
-// not tuned further -- these modes are not on BASELINE.json's metric.  Forward only: training of these modes runs the
-// chunked torch restatement (autograd).
+// not tuned further -- these modes are not on BASELINE.json's metric.  et_epipolar_backward_general (below) is its
+// backward for the branches without a prior.
 #include "et_common.h"
 
 namespace {
@@ -38,6 +38,7 @@ struct GeneralParams {
 constexpr int kGenWaves = 4;        // waves (= reference pixels) per block
 constexpr int kGenMaxQ = 8;         // query channels a lane keeps in registers: cs <= 512
 constexpr int gen_wave_floats(int K) { return (K * 9 + 3) & ~3; }   // 36 bytes per sample, 16-byte aligned per wave
+constexpr int gen_bwd_wave_floats(int K) { return (K * 10 + 3) & ~3; }   // + a second [K'] array
 constexpr size_t gen_lds_bytes(int K) { return (size_t)kGenWaves * gen_wave_floats(K) * sizeof(float); }
 
 // one channel of one bilinear sample: tap[r] < 0 <=> outside the image (weight 0, zero padding)
@@ -214,6 +215,210 @@ __global__ __launch_bounds__(kWave *kGenWaves) void epipolar_fwd_general_kernel(
     }
 }
 
+// ---- backward of the same branches (no PRIOR): d q, d map_sim, d map_val from d out ---------------------------------
+// One wave per reference pixel again.  With s_k' = q . P_k' (P: pooled similarity samples), a = soft-max(scale mask(s))
+// (or mask(s) / K'), out = sum_k' a_k' V_k' (V: pooled value samples) and g = d out:
+//     d a_k' = g . V_k'                     d s_k' = scale a_k' (d a_k' - sum_j a_j d a_j)     (0 under the mask;
+//     d q    = sum_k' d s_k' P_k'                                                               d a_k' / K' without soft-max)
+//     d P_k' = d s_k' q ,  d V_k' = a_k' g  -> through the per-channel maximum to the sample that won (the first on a
+//     tie, as torch.max) -> times the four bilinear weights onto the taps of the maps: float atomics (the sums over
+//     pixels arrive in any order: reproducible to rounding only, like the tile backward).
+// The similarities are recomputed (nothing but the inputs is saved by the forward).
+struct GeneralBwdParams {
+    GeneralParams f;        // inputs as in the forward (out / attn / corr / prior unused)
+    const float *gout;      // (N, H*W, cv)
+    float *gq;              // (N, H*W, cs)  written
+    float *gsim;            // (N, H*W, cs)  nullable, accumulated with atomics: zero it first
+    float *gval;            // (N, H*W, cv)  nullable, accumulated with atomics: zero it first
+};
+
+__device__ __forceinline__ void gen_scatter(float *gmap, int ch, int c, const int4 t, const float4 w, float g)
+{
+    if (t.x >= 0) unsafeAtomicAdd(gmap + (size_t)t.x * ch + c, g * w.x);
+    if (t.y >= 0) unsafeAtomicAdd(gmap + (size_t)t.y * ch + c, g * w.y);
+    if (t.z >= 0) unsafeAtomicAdd(gmap + (size_t)t.z * ch + c, g * w.z);
+    if (t.w >= 0) unsafeAtomicAdd(gmap + (size_t)t.w * ch + c, g * w.w);
+}
+
+template <bool POOL>
+__global__ __launch_bounds__(kWave *kGenWaves) void epipolar_bwd_general_kernel(const GeneralBwdParams bp)
+{
+    extern __shared__ float s_dyn[];
+    const GeneralParams &p = bp.f;
+    const EtLayerDesc &d = p.d;
+    const int H = d.H, W = d.W, K = d.K, HW = H * W;
+    const int Ks = POOL ? K / 2 : K;
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const long long gp = (long long)blockIdx.x * kGenWaves + wave;
+    const int n = (int)(gp / HW);
+    if (n >= d.N) return;
+    const int pix = (int)(gp - (long long)n * HW);
+    const int h = pix / W, w = pix - h * W;
+    float4 *s_w = reinterpret_cast<float4 *>(s_dyn + (size_t)wave * gen_bwd_wave_floats(K));
+    int4 *s_tap = reinterpret_cast<int4 *>(s_w + K);
+    float *s_sim = reinterpret_cast<float *>(s_tap + K);   // [K'] similarity, then d s
+    float *s_a = s_sim + K;                                 // [K'] d a, then a
+    const float neg_inf = -__builtin_huge_valf();
+
+    const et::Segment seg = et::epipolar_segment(d, p.cam + (size_t)n * ET_CAM_STRIDE, p.xs[w], p.ys[h]);
+    for (int k = lane; k < K; k += kWave) {
+        const et::SampleSetup su = et::sample_setup(d, seg, p.steps[k]);
+        s_w[k] = make_float4(su.weight[0], su.weight[1], su.weight[2], su.weight[3]);
+        s_tap[k] = make_int4(su.tap[0], su.tap[1], su.tap[2], su.tap[3]);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+
+    const float *qrow = p.q + ((size_t)n * HW + pix) * p.cs;
+    const float *grow = bp.gout + ((size_t)n * HW + pix) * p.cv;
+    const float *m1 = p.m_sim + (size_t)n * HW * p.cs;
+    const float *m2 = p.m_val + (size_t)n * HW * p.cv;
+    float qv[kGenMaxQ];
+#pragma unroll
+    for (int i = 0; i < kGenMaxQ; ++i) qv[i] = (lane + i * kWave < p.cs) ? qrow[lane + i * kWave] : 0.f;
+
+    // ---- lanes <-> channels: s_k' = q . P_k'  and  d a_k' = g . V_k' ------------------------------------------------
+    for (int k = 0; k < Ks; ++k) {
+        const int4 t0 = s_tap[k];
+        const float4 w0 = s_w[k];
+        int4 t1 = t0;
+        float4 w1 = w0;
+        if (POOL) {
+            t1 = s_tap[k + Ks];
+            w1 = s_w[k + Ks];
+        }
+        float dot = 0.f, da = 0.f;
+#pragma unroll
+        for (int i = 0; i < kGenMaxQ; ++i) {
+            const int c = lane + i * kWave;
+            if (c < p.cs) {
+                float v = gen_sample(m1, p.cs, c, t0, w0);
+                if (POOL) v = fmaxf(v, gen_sample(m1, p.cs, c, t1, w1));
+                dot = fmaf(qv[i], v, dot);
+            }
+        }
+        for (int c = lane; c < p.cv; c += kWave) {
+            float v = gen_sample(m2, p.cv, c, t0, w0);
+            if (POOL) v = fmaxf(v, gen_sample(m2, p.cv, c, t1, w1));
+            da = fmaf(grow[c], v, da);
+        }
+        dot = wave_all_sum(dot);
+        da = wave_all_sum(da);
+        if (lane == 0) {
+            s_sim[k] = dot;
+            s_a[k] = da;
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+
+    // ---- lanes <-> samples: a (recomputed) and d s ---------------------------------------------------------------------
+    {
+        constexpr int KPL = 4;
+        float l[KPL], a[KPL], da[KPL];
+        bool masked[KPL];
+        float vmax = neg_inf;
+#pragma unroll
+        for (int s = 0; s < KPL; ++s) {
+            const int k = s * kWave + lane;
+            const bool in = k < Ks;
+            float v = in ? s_sim[k] : 0.f;
+            masked[s] = (v == 0.f);
+            v = masked[s] ? -1e10f : v;
+            v = d.softmax_enabled ? v * d.softmax_scale : v / (float)Ks;
+            l[s] = v;
+            da[s] = in ? s_a[k] : 0.f;
+            if (in) vmax = fmaxf(vmax, v);
+        }
+        float ds[KPL];
+        if (d.softmax_enabled) {
+            vmax = wave_all_max(vmax);
+            float sum = 0.f;
+#pragma unroll
+            for (int s = 0; s < KPL; ++s) {
+                a[s] = (s * kWave + lane < Ks) ? expf(l[s] - vmax) : 0.f;
+                sum += a[s];
+            }
+            sum = wave_all_sum(sum);
+            float ada = 0.f;
+#pragma unroll
+            for (int s = 0; s < KPL; ++s) {
+                a[s] = a[s] / sum;
+                ada = fmaf(a[s], da[s], ada);
+            }
+            ada = wave_all_sum(ada);
+#pragma unroll
+            for (int s = 0; s < KPL; ++s) ds[s] = masked[s] ? 0.f : d.softmax_scale * a[s] * (da[s] - ada);
+        } else {
+#pragma unroll
+            for (int s = 0; s < KPL; ++s) {
+                a[s] = (s * kWave + lane < Ks) ? l[s] : 0.f;
+                ds[s] = masked[s] ? 0.f : da[s] / (float)Ks;
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < KPL; ++s) {
+            const int k = s * kWave + lane;
+            if (k < Ks) {
+                s_sim[k] = ds[s];
+                s_a[k] = a[s];
+            }
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+
+    // ---- lanes <-> channels: d q, and the scatter of d P / d V through the maximum onto the maps ------------------------
+    {
+        float dq[kGenMaxQ];
+#pragma unroll
+        for (int i = 0; i < kGenMaxQ; ++i) dq[i] = 0.f;
+        float *g1 = bp.gsim ? bp.gsim + (size_t)n * HW * p.cs : nullptr;
+        float *g2 = bp.gval ? bp.gval + (size_t)n * HW * p.cv : nullptr;
+        for (int k = 0; k < Ks; ++k) {
+            const float dsk = s_sim[k], ak = s_a[k];
+            const int4 t0 = s_tap[k];
+            const float4 w0 = s_w[k];
+            int4 t1 = t0;
+            float4 w1 = w0;
+            if (POOL) {
+                t1 = s_tap[k + Ks];
+                w1 = s_w[k + Ks];
+            }
+            if (dsk != 0.f) {    // wave-uniform
+#pragma unroll
+                for (int i = 0; i < kGenMaxQ; ++i) {
+                    const int c = lane + i * kWave;
+                    if (c < p.cs) {
+                        const float v0 = gen_sample(m1, p.cs, c, t0, w0);
+                        bool second = false;
+                        float v = v0;
+                        if (POOL) {
+                            const float v1 = gen_sample(m1, p.cs, c, t1, w1);
+                            second = v1 > v0;
+                            v = second ? v1 : v0;
+                        }
+                        dq[i] = fmaf(dsk, v, dq[i]);
+                        if (g1) gen_scatter(g1, p.cs, c, second ? t1 : t0, second ? w1 : w0, dsk * qv[i]);
+                    }
+                }
+            }
+            if (g2 && ak != 0.f) {
+                for (int c = lane; c < p.cv; c += kWave) {
+                    bool second = false;
+                    if (POOL) second = gen_sample(m2, p.cv, c, t1, w1) > gen_sample(m2, p.cv, c, t0, w0);
+                    gen_scatter(g2, p.cv, c, second ? t1 : t0, second ? w1 : w0, ak * grow[c]);
+                }
+            }
+        }
+        float *gqrow = bp.gq + ((size_t)n * HW + pix) * p.cs;
+#pragma unroll
+        for (int i = 0; i < kGenMaxQ; ++i)
+            if (lane + i * kWave < p.cs) gqrow[lane + i * kWave] = dq[i];
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -250,6 +455,40 @@ int et_epipolar_forward_general(const EtLayerDesc *desc, const float *xs, const 
     if (pool) hipLaunchKernelGGL(epipolar_fwd_general_kernel<true>, dim3((unsigned)blocks), dim3(kWave * kGenWaves), lds, st, p);
     else hipLaunchKernelGGL(epipolar_fwd_general_kernel<false>, dim3((unsigned)blocks), dim3(kWave * kGenWaves), lds, st, p);
     return check_launch("et_epipolar_forward_general");
+}
+
+int et_epipolar_backward_general(const EtLayerDesc *desc, const float *xs, const float *ys, const float *steps,
+                                 const float *cam, const float *q, const float *map_sim, const float *map_val,
+                                 const float *grad_out, int c_sim, int c_val, int flags, float *grad_q,
+                                 float *grad_map_sim, float *grad_map_val, void *stream)
+{
+    if (!desc) return fail("et_epipolar_backward_general: desc is NULL");
+    EtLayerDesc chk = *desc;
+    chk.C = 4;
+    if (int e = validate(&chk)) return e;
+    if (!xs || !ys || !steps || !cam || !q || !map_sim || !map_val || !grad_out || !grad_q)
+        return fail("et_epipolar_backward_general: NULL pointer");
+    if (c_sim <= 0 || c_sim > kGenMaxQ * kWave) return fail("et_epipolar_backward_general: c_sim=%d outside [1, %d]", c_sim, kGenMaxQ * kWave);
+    if (c_val <= 0 || c_val > 4096) return fail("et_epipolar_backward_general: c_val=%d outside [1, 4096]", c_val);
+    if (flags & ~ET_GENERAL_POOLING) return fail("et_epipolar_backward_general: only ET_GENERAL_POOLING is supported (flags=%d)", flags);
+    const bool pool = flags & ET_GENERAL_POOLING;
+    if (pool && (desc->K & 1)) return fail("et_epipolar_backward_general: POOLING needs an even K (K=%d)", desc->K);
+    const long long hw = (long long)desc->H * desc->W;
+    if (hw * (c_sim > c_val ? c_sim : c_val) * 4 >= (1LL << 31)) return fail("one feature map must stay below 2 GiB");
+    GeneralBwdParams bp;
+    bp.f.d = *desc;
+    bp.f.xs = xs; bp.f.ys = ys; bp.f.steps = steps; bp.f.cam = cam;
+    bp.f.q = q; bp.f.m_sim = map_sim; bp.f.m_val = map_val; bp.f.prior = nullptr;
+    bp.f.out = nullptr; bp.f.attn = nullptr; bp.f.corr = nullptr;
+    bp.f.cs = c_sim; bp.f.cv = c_val; bp.f.prior_mul = 0;
+    bp.gout = grad_out; bp.gq = grad_q; bp.gsim = grad_map_sim; bp.gval = grad_map_val;
+    const long long blocks = (hw * desc->N + kGenWaves - 1) / kGenWaves;
+    if (blocks > 0x7fffffffLL) return fail("grid too large");
+    const size_t lds = (size_t)kGenWaves * gen_bwd_wave_floats(desc->K) * sizeof(float);
+    hipStream_t st = (hipStream_t)stream;
+    if (pool) hipLaunchKernelGGL(epipolar_bwd_general_kernel<true>, dim3((unsigned)blocks), dim3(kWave * kGenWaves), lds, st, bp);
+    else hipLaunchKernelGGL(epipolar_bwd_general_kernel<false>, dim3((unsigned)blocks), dim3(kWave * kGenWaves), lds, st, bp);
+    return check_launch("et_epipolar_backward_general");
 }
 
 }  // extern "C"

@@ -122,9 +122,10 @@ class Epipolar(nn.Module):
         return tuple(torch.cat([p[i] for p in parts]) for i in range(3))
 
     def _general_kernel_applies(self, feat1, feat2, ref1=None, ref2=None) -> bool:
-        """True when `et_epipolar_forward_general` computes this call: ATTENTION avg over a dot-product similarity of
-        feature maps (theta / phi / g, BOTTLENECK, POOLING, PRIOR / PRIORMUL in any combination), and nothing asks for a
-        gradient -- the kernel is forward only, training of these modes takes the chunked torch restatement below."""
+        """True when the HIP general kernels compute this call: ATTENTION avg over a dot-product similarity of feature maps
+        (theta / phi / g, BOTTLENECK, POOLING in any combination; PRIOR / PRIORMUL too, but only when nothing asks for a
+        gradient -- `et_epipolar_backward_general` has no prior term, training with a prior takes the chunked torch
+        restatement below)."""
         e = self.cfg.EPIPOLAR
         if not (e.ATTENTION == "avg" and e.SIMILARITY == "dot" and e.FIND_CORR == "feature" and ref1 is None and ref2 is None):
             return False
@@ -132,31 +133,33 @@ class Epipolar(nn.Module):
             return False
         if e.POOLING and self.sample_size % 2:
             return False
-        if torch.is_grad_enabled():
+        if e.PRIOR and torch.is_grad_enabled():
             params = [q for k in ("theta", "phi", "g") if k in e.PARAMETERIZED for q in getattr(self, k).parameters()]
-            if e.PRIOR:
-                params += list(self.prior.values())
+            params += list(self.prior.values())
             if feat1.requires_grad or feat2.requires_grad or any(q.requires_grad for q in params):
                 return False
         c_sim = feat1.shape[1] // (e.BOTTLENECK if "theta" in e.PARAMETERIZED else 1)
         return c_sim <= 512
 
     def _attend_general_hip(self, feat1, feat2, P1, P2, camera=None, other_camera=None):
-        """The parameterised / pooled / prior branches through ONE HIP kernel (ops.forward_general_nhwc): the 1x1
-        convolutions act on the maps (epipolar.py:138-153: torch / MIOpen GEMMs), the kernel samples, pools, masks,
-        soft-maxes and sums without materialising a K x C x H x W tensor."""
+        """The parameterised / pooled / prior branches through the HIP general kernels: the 1x1 convolutions act on the
+        maps (epipolar.py:138-153: torch / MIOpen GEMMs, with autograd), the kernel samples, pools, masks, soft-maxes and
+        sums without materialising a K x C x H x W tensor (`ops.GeneralAttend`; with a prior `ops.forward_general_nhwc`,
+        forward only)."""
         e = self.cfg.EPIPOLAR
+        other1 = feat2 if "other1" in e.OTHER_GRAD else feat2.detach()                  # :138-141
+        other2 = feat2 if "other2" in e.OTHER_GRAD else feat2.detach()                  # :147-150
+        q = self.theta(feat1) if "theta" in e.PARAMETERIZED else feat1                  # :144-145
+        m1 = self.phi(other1) if "phi" in e.PARAMETERIZED else other1                   # :142-143
+        m2 = self.g(other2) if "g" in e.PARAMETERIZED else other2                       # :152-153
         with torch.no_grad():
-            q = self.theta(feat1) if "theta" in e.PARAMETERIZED else feat1                  # :144-145
-            m1 = self.phi(feat2) if "phi" in e.PARAMETERIZED else feat2                     # :142-143
-            m2 = self.g(feat2) if "g" in e.PARAMETERIZED else feat2                         # :152-153
-            prior = None
-            if e.PRIOR:                                                                     # :288-289, :300-301
-                prior = torch.stack([self.prior[(int(a), int(b))].to(q) for a, b in zip(camera, other_camera)]).contiguous()
             cam = self._cam(P1, P2, feat2.device)
+        if not e.PRIOR:
+            return ops.GeneralAttend.apply(q, m1, m2, cam, self.layer_spec(), bool(e.POOLING))
+        with torch.no_grad():                                                           # :288-289, :300-301, :308-309
+            prior = torch.stack([self.prior[(int(a), int(b))].to(q) for a, b in zip(camera, other_camera)]).contiguous()
             out, attn, corr_pos = ops.forward_general_nhwc(self.layer_spec(), ops.to_nhwc(q), ops.to_nhwc(m1), ops.to_nhwc(m2),
-                                                           cam, prior=prior, pooling=bool(e.POOLING),
-                                                           prior_mul=bool(e.PRIOR and e.PRIORMUL))
+                                                           cam, prior=prior, pooling=bool(e.POOLING), prior_mul=bool(e.PRIORMUL))
         return out.permute(0, 3, 1, 2), attn, corr_pos
 
     def _attend_general_chunk(self, feat1, feat2, P1, P2, camera=None, other_camera=None, ref1=None, ref2=None):

@@ -155,6 +155,52 @@ def forward_general_nhwc(spec: LayerSpec, q: torch.Tensor, map_sim: torch.Tensor
     return out, attn, corr
 
 
+def backward_general_nhwc(spec: LayerSpec, q, map_sim, map_val, cam, grad_out, pooling=False, need_sim=True, need_val=True):
+    """Backward of forward_general_nhwc (no prior): returns (grad_q, grad_map_sim | None, grad_map_val | None), NHWC.
+    The map gradients are accumulated with float atomics (reproducible to rounding only)."""
+    for t, nm in ((q, "q"), (map_sim, "map_sim"), (map_val, "map_val"), (cam, "cam"), (grad_out, "grad_out")):
+        _require_gpu(t, nm)
+    n, h, w, cs = q.shape
+    cv = map_val.shape[-1]
+    if tuple(grad_out.shape) != (n, h, w, cv) or not grad_out.is_contiguous():
+        raise ValueError("grad_out must be a contiguous (N,H,W,Cv) tensor")
+    if not (q.is_contiguous() and map_sim.is_contiguous() and map_val.is_contiguous()):
+        raise ValueError("q / map_sim / map_val must be contiguous (N,H,W,C) tensors")
+    xs, ys, steps = spec.constants(q.device)
+    gq = torch.empty_like(q)
+    gsim = torch.zeros_like(map_sim) if need_sim else None
+    gval = torch.zeros_like(map_val) if need_val else None
+    d = spec.desc(n, 4)
+    with torch.cuda.device(q.device):
+        _lib.check(_lib.load().et_epipolar_backward_general(
+            ctypes.byref(d), _ptr(xs), _ptr(ys), _ptr(steps), _ptr(cam), _ptr(q), _ptr(map_sim), _ptr(map_val),
+            _ptr(grad_out), cs, cv, _lib.ET_GENERAL_POOLING if pooling else 0, _ptr(gq), _ptr(gsim), _ptr(gval),
+            _stream(q)), "et_epipolar_backward_general")
+    return gq, gsim, gval
+
+
+class GeneralAttend(torch.autograd.Function):
+    """The parameterised / pooled branches (no prior) with autograd: logical NCHW in and out, `attn` and `corr_pos`
+    without gradient (as EpipolarAttend)."""
+
+    @staticmethod
+    def forward(ctx, q, map_sim, map_val, cam, spec: LayerSpec, pooling: bool):
+        qn, m1, m2 = to_nhwc(q), to_nhwc(map_sim), to_nhwc(map_val)
+        out, attn, corr = forward_general_nhwc(spec, qn, m1, m2, cam, pooling=pooling)
+        ctx.spec, ctx.pooling = spec, pooling
+        ctx.save_for_backward(qn, m1, m2, cam)
+        ctx.mark_non_differentiable(attn, corr)
+        return out.permute(0, 3, 1, 2), attn, corr
+
+    @staticmethod
+    def backward(ctx, grad_out, _ga, _gc):
+        qn, m1, m2, cam = ctx.saved_tensors
+        gq, gs, gv = backward_general_nhwc(ctx.spec, qn, m1, m2, cam, to_nhwc(grad_out), ctx.pooling,
+                                           need_sim=ctx.needs_input_grad[1], need_val=ctx.needs_input_grad[2])
+        nchw = lambda t: None if t is None else t.permute(0, 3, 1, 2)
+        return nchw(gq) if ctx.needs_input_grad[0] else None, nchw(gs), nchw(gv), None, None, None
+
+
 _TILE_BITS = (_lib.ET_VARIANT_TILE_SPLIT | _lib.ET_VARIANT_TILE_CLASSIC | _lib.ET_VARIANT_WS_V2 |
               _lib.ET_VARIANT_WS_SETPRIO)      # variant bits that tune the tile path instead of leaving it
 

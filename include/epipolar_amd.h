@@ -150,7 +150,7 @@ int et_epipolar_forward_tiled(const EtLayerDesc *desc, const float *xs, const fl
                               float *attn, float *corr_pos, const float *res_bias, float *res_base,
                               void *workspace, size_t workspace_bytes, void *stream);
 
-/* The operator's parameterised / pooled / prior branches as one kernel, forward only.
+/* The operator's parameterised / pooled / prior branches as one kernel.
  * The reference applies its optional 1x1 convolutions to the maps BEFORE sampling (epipolar.py:138-153), so these
  * branches are the headline operator over three tensors instead of two:
  *   q        : (N,H,W,c_sim)  feat1 or theta(feat1)                          (epipolar.py:144-145)
@@ -172,6 +172,18 @@ int et_epipolar_forward_general(const EtLayerDesc *desc, const float *xs, const 
                                 const float *cam, const float *q, const float *map_sim, const float *map_val,
                                 const float *prior, int c_sim, int c_val, int flags, float *out, float *attn,
                                 float *corr_pos, void *stream);
+
+/* Backward of et_epipolar_forward_general w.r.t. its three tensors, for the branches without a prior (flags:
+ * ET_GENERAL_POOLING only):  grad_out (N,H,W,c_val)  ->  grad_q (N,H,W,c_sim), written;  grad_map_sim (N,H,W,c_sim) and
+ * grad_map_val (N,H,W,c_val), each nullable (OTHER_GRAD without 'other1' / 'other2', epipolar.py:138-150) and
+ * ACCUMULATED with float atomics -- the caller zeroes them first; sums over pixels arrive in any order, so the result
+ * is reproducible to rounding only.  The similarities and the soft-max are recomputed from the inputs; the gradient of
+ * POOLING's per-channel maximum goes to the sample that won (the first on a tie, as torch.max).  Gradients through the
+ * `attn` / `corr_pos` outputs are not provided (the reference configurations never use them). */
+int et_epipolar_backward_general(const EtLayerDesc *desc, const float *xs, const float *ys, const float *steps,
+                                 const float *cam, const float *q, const float *map_sim, const float *map_val,
+                                 const float *grad_out, int c_sim, int c_val, int flags, float *grad_q,
+                                 float *grad_map_sim, float *grad_map_val, void *stream);
 
 /* Backward of et_epipolar_forward w.r.t. both feature maps (sample locations
  * carry no gradient, epipolar.py:178-183).  Everything is recomputed from the

@@ -236,13 +236,59 @@ def test_general_kernel_vs_torch_restatement(case):
     assert_corr_pos(locs, corr_h.cpu().numpy(), corr_t.cpu().numpy(), attn_h.cpu().numpy(), True, tie=2e-6, max_frac=2e-2)
 
 
-def test_general_kernel_is_not_taken_when_a_gradient_is_requested():
+def test_general_kernel_routing():
+    """With a gradient requested the parameterised / pooled branches still run on the HIP kernels (ops.GeneralAttend);
+    the prior branches (no prior term in the HIP backward) take the torch restatement then."""
     d = np.load(os.path.join(GOLDEN_DIR, "modes", "param_pool_c16_k16.npz"))
     mod = _module(d)
+    f1, f2 = torch.from_numpy(d["feat1"]).cuda().requires_grad_(True), torch.from_numpy(d["feat2"]).cuda()
+    assert mod._general_kernel_applies(f1, f2)
+    d = np.load(os.path.join(GOLDEN_DIR, "modes", "prior_add_c8_k8.npz"))
+    mod = _module(d)
     f1, f2 = torch.from_numpy(d["feat1"]).cuda(), torch.from_numpy(d["feat2"]).cuda()
-    assert not mod._general_kernel_applies(f1, f2)                     # parameters of theta / phi / g require a gradient
+    assert not mod._general_kernel_applies(f1.requires_grad_(True), f2)
     with torch.no_grad():
         assert mod._general_kernel_applies(f1, f2)
-    for q in mod.parameters():
-        q.requires_grad_(False)
-    assert mod._general_kernel_applies(f1, f2) and not mod._general_kernel_applies(f1.requires_grad_(True), f2)
+
+
+@pytest.mark.parametrize("case", [
+    dict(H=24, C=64, K=33, N=3, bottleneck=2, pooling=False, softmax=True),
+    dict(H=16, C=32, K=130, N=2, bottleneck=4, pooling=True, softmax=True),
+    dict(H=16, C=16, K=12, N=2, bottleneck=1, pooling=True, softmax=False),
+    dict(H=16, C=16, K=8, N=2, bottleneck=1, pooling=False, softmax=True, other_grad=("other2",)),
+])
+def test_general_kernel_gradients_vs_torch_restatement(case):
+    """ops.GeneralAttend (HIP forward + HIP backward, float atomics) against autograd through the torch restatement:
+    gradients of both feature maps and of the theta / phi / g convolutions."""
+    from epipolar_transformers_amd import default_cfg, synthetic as syn
+    from epipolar_transformers_amd.epipolar import Epipolar
+
+    H, C, K, N = case["H"], case["C"], case["K"], case["N"]
+    par = ("z", "theta", "phi", "g")
+    cfg = default_cfg()
+    cfg.merge_from_list(["KEYPOINT.HEATMAP_SIZE", (H, H), "KEYPOINT.NFEATS", C, "EPIPOLAR.SAMPLESIZE", K,
+                         "DATASETS.IMAGE_SIZE", (4 * H, 4 * H), "EPIPOLAR.USE_CORRECT_NORMALIZE", True,
+                         "EPIPOLAR.ATTENTION", "avg", "EPIPOLAR.PARAMETERIZED", par, "EPIPOLAR.BOTTLENECK", case["bottleneck"],
+                         "EPIPOLAR.ZRESIDUAL", case["bottleneck"] == 1, "EPIPOLAR.POOLING", case["pooling"],
+                         "EPIPOLAR.SOFTMAX_ENABLED", case["softmax"], "EPIPOLAR.OTHER_GRAD", case.get("other_grad", ("other1", "other2"))])
+    torch.manual_seed(3)
+    mod = Epipolar(cfg=cfg).cuda().eval()
+    with torch.no_grad():
+        for nm in ("theta", "phi", "g"):
+            getattr(mod, nm).weight.normal_(0, 0.3)
+            getattr(mod, nm).bias.normal_(0, 0.3)
+    P1, P2 = syn.make_pairs(1, 4, 4 * H, seed=21, jitter=(0.05, 4.0))
+    P1, P2 = P1[:N], P2[:N]
+    f1, f2 = syn.make_features(N, C, H, H, seed=22)
+    gout = torch.randn(N, C // case["bottleneck"], H, H, device="cuda")
+    grads = []
+    for path in ("hip", "torch"):
+        a, b = f1.cuda().requires_grad_(True), f2.cuda().requires_grad_(True)
+        mod.zero_grad()
+        assert mod._general_kernel_applies(a, b)
+        out, attn, corr = (mod._attend_general if path == "hip" else mod._attend_general_chunk)(a, b, P1, P2)
+        (out * gout).sum().backward()
+        grads.append([a.grad.clone(), b.grad.clone()] + [q.grad.clone() for nm in ("theta", "phi", "g") for q in getattr(mod, nm).parameters()])
+    names = ["feat1", "feat2", "theta.w", "theta.b", "phi.w", "phi.b", "g.w", "g.b"]
+    for nm, gh, gt in zip(names, *grads):
+        assert (gh - gt).abs().max().item() <= 2e-4 * max(gt.abs().max().item(), 1e-6), nm
