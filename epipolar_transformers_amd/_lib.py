@@ -34,6 +34,8 @@ ET_VARIANT_WS_SETPRIO = 262144
 ET_ABI_VERSION = 10
 ET_GENERAL_POOLING = 1
 ET_GENERAL_PRIOR_MUL = 2
+ET_GENERAL_COSINE = 4
+ET_GENERAL_ATTENTION_MAX = 8
 
 
 class EpipolarAmdError(RuntimeError):

@@ -33,6 +33,8 @@ struct GeneralParams {
     float *attn;            // (N, K', H*W) or NULL
     float *corr;            // (N, H*W, 2) or NULL
     int cs, cv, prior_mul;
+    int cosine;             // similarity = cosine of q and the (pooled) sample (F.cosine_similarity, eps 1e-8) instead of the dot product
+    int attn_max;           // ATTENTION max: raw cosine similarity, no mask / soft-max; out = the arg-max sample's values
 };
 
 constexpr int kGenWaves = 4;        // waves (= reference pixels) per block
@@ -88,6 +90,12 @@ __global__ __launch_bounds__(kWave *kGenWaves) void epipolar_fwd_general_kernel(
         float qv[kGenMaxQ];
 #pragma unroll
         for (int i = 0; i < kGenMaxQ; ++i) qv[i] = (lane + i * kWave < p.cs) ? qrow[lane + i * kWave] : 0.f;
+        float qq = 0.f;
+        if (p.cosine) {
+#pragma unroll
+            for (int i = 0; i < kGenMaxQ; ++i) qq = fmaf(qv[i], qv[i], qq);
+            qq = wave_all_sum(qq);
+        }
         for (int k = 0; k < Ks; ++k) {
             const int4 t0 = s_tap[k];
             const float4 w0 = s_w[k];
@@ -97,7 +105,7 @@ __global__ __launch_bounds__(kWave *kGenWaves) void epipolar_fwd_general_kernel(
                 t1 = s_tap[k + Ks];
                 w1 = s_w[k + Ks];
             }
-            float dot = 0.f;
+            float dot = 0.f, vv = 0.f;
 #pragma unroll
             for (int i = 0; i < kGenMaxQ; ++i) {
                 const int c = lane + i * kWave;
@@ -105,9 +113,14 @@ __global__ __launch_bounds__(kWave *kGenWaves) void epipolar_fwd_general_kernel(
                     float v = gen_sample(m1, p.cs, c, t0, w0);
                     if (POOL) v = fmaxf(v, gen_sample(m1, p.cs, c, t1, w1));
                     dot = fmaf(qv[i], v, dot);
+                    vv = fmaf(v, v, vv);
                 }
             }
             dot = wave_all_sum(dot);
+            if (p.cosine) {   // epipolar.py:282-286 / :290-293: x1 . x2 / (max(|x1|, eps) max(|x2|, eps)), eps = 1e-8
+                vv = wave_all_sum(vv);
+                dot = dot / (fmaxf(sqrtf(qq), 1e-8f) * fmaxf(sqrtf(vv), 1e-8f));
+            }
             if (lane == 0) s_sim[k] = dot;
         }
     }
@@ -124,14 +137,16 @@ __global__ __launch_bounds__(kWave *kGenWaves) void epipolar_fwd_general_kernel(
             const int k = s * kWave + lane;
             const bool in = k < Ks;
             float v = in ? s_sim[k] : 0.f;
-            v = (v == 0.f) ? -1e10f : v;                                          // epipolar.py:298
             pr[s] = (in && p.prior) ? p.prior[((size_t)n * Ks + k) * HW + pix] : 0.f;
-            if (p.prior && !p.prior_mul) v += pr[s];                              // :300-301
-            v = d.softmax_enabled ? v * d.softmax_scale : v / (float)Ks;          // :306 / :311
+            if (!p.attn_max) {                                                    // (ATTENTION max: the raw cosine, :282-286)
+                v = (v == 0.f) ? -1e10f : v;                                      // epipolar.py:298
+                if (p.prior && !p.prior_mul) v += pr[s];                          // :300-301
+                v = d.softmax_enabled ? v * d.softmax_scale : v / (float)Ks;      // :306 / :311
+            }
             l[s] = v;
             if (in) vmax = fmaxf(vmax, v);
         }
-        if (d.softmax_enabled) {
+        if (d.softmax_enabled && !p.attn_max) {
             vmax = wave_all_max(vmax);
             float sum = 0.f;
 #pragma unroll
@@ -165,7 +180,8 @@ __global__ __launch_bounds__(kWave *kGenWaves) void epipolar_fwd_general_kernel(
         for (int s = 0; s < KPL; ++s) {
             const int k = s * kWave + lane;
             if (k < Ks) {
-                s_sim[k] = a[s];
+                // ATTENTION max gathers the arg-max sample (epipolar.py:232-235): a one-hot weight for the sum below
+                s_sim[k] = p.attn_max ? (k == besti ? 1.f : 0.f) : a[s];
                 if (p.attn) p.attn[((size_t)n * Ks + k) * HW + pix] = a[s];
             }
         }
@@ -188,6 +204,7 @@ __global__ __launch_bounds__(kWave *kGenWaves) void epipolar_fwd_general_kernel(
             float acc[4] = {0.f, 0.f, 0.f, 0.f};
             for (int k = 0; k < Ks; ++k) {
                 const float ak = s_sim[k];
+                if (p.attn_max && ak == 0.f) continue;      // wave-uniform (the one-hot weights of ATTENTION max)
                 const int4 t0 = s_tap[k];
                 const float4 w0 = s_w[k];
                 int4 t1 = t0;
@@ -436,7 +453,9 @@ int et_epipolar_forward_general(const EtLayerDesc *desc, const float *xs, const 
         return fail("et_epipolar_forward_general: NULL pointer");
     if (c_sim <= 0 || c_sim > kGenMaxQ * kWave) return fail("et_epipolar_forward_general: c_sim=%d outside [1, %d]", c_sim, kGenMaxQ * kWave);
     if (c_val <= 0 || c_val > 4096) return fail("et_epipolar_forward_general: c_val=%d outside [1, 4096]", c_val);
-    if (flags & ~(ET_GENERAL_POOLING | ET_GENERAL_PRIOR_MUL)) return fail("et_epipolar_forward_general: unknown flag bits %d", flags);
+    if (flags & ~(ET_GENERAL_POOLING | ET_GENERAL_PRIOR_MUL | ET_GENERAL_COSINE | ET_GENERAL_ATTENTION_MAX))
+        return fail("et_epipolar_forward_general: unknown flag bits %d", flags);
+    if ((flags & ET_GENERAL_ATTENTION_MAX) && prior) return fail("et_epipolar_forward_general: ATTENTION max takes no prior");
     const bool pool = flags & ET_GENERAL_POOLING;
     if (pool && (desc->K & 1)) return fail("et_epipolar_forward_general: POOLING needs an even K (K=%d)", desc->K);
     if ((flags & ET_GENERAL_PRIOR_MUL) && !prior) return fail("et_epipolar_forward_general: PRIOR_MUL without a prior");
@@ -448,6 +467,8 @@ int et_epipolar_forward_general(const EtLayerDesc *desc, const float *xs, const 
     p.q = q; p.m_sim = map_sim; p.m_val = map_val; p.prior = prior;
     p.out = out; p.attn = attn; p.corr = corr_pos;
     p.cs = c_sim; p.cv = c_val; p.prior_mul = (flags & ET_GENERAL_PRIOR_MUL) ? 1 : 0;
+    p.attn_max = (flags & ET_GENERAL_ATTENTION_MAX) ? 1 : 0;
+    p.cosine = (flags & (ET_GENERAL_COSINE | ET_GENERAL_ATTENTION_MAX)) ? 1 : 0;   // (ATTENTION max is always cosine, epipolar.py:282)
     const long long blocks = (hw * desc->N + kGenWaves - 1) / kGenWaves;
     if (blocks > 0x7fffffffLL) return fail("grid too large");
     const size_t lds = gen_lds_bytes(desc->K);
@@ -480,7 +501,7 @@ int et_epipolar_backward_general(const EtLayerDesc *desc, const float *xs, const
     bp.f.xs = xs; bp.f.ys = ys; bp.f.steps = steps; bp.f.cam = cam;
     bp.f.q = q; bp.f.m_sim = map_sim; bp.f.m_val = map_val; bp.f.prior = nullptr;
     bp.f.out = nullptr; bp.f.attn = nullptr; bp.f.corr = nullptr;
-    bp.f.cs = c_sim; bp.f.cv = c_val; bp.f.prior_mul = 0;
+    bp.f.cs = c_sim; bp.f.cv = c_val; bp.f.prior_mul = 0; bp.f.cosine = 0; bp.f.attn_max = 0;
     bp.gout = grad_out; bp.gq = grad_q; bp.gsim = grad_map_sim; bp.gval = grad_map_val;
     const long long blocks = (hw * desc->N + kGenWaves - 1) / kGenWaves;
     if (blocks > 0x7fffffffLL) return fail("grid too large");

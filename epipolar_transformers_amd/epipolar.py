@@ -109,7 +109,7 @@ class Epipolar(nn.Module):
         materialises per PAIR, epipolar.py:199-213) never exceed ~2 GB at once however large the batch is
         (keypoint_h36m_param.yaml at 32 frames x 4 views would otherwise hold 17 GB per sampled map)."""
         if self._general_kernel_applies(feat1, feat2, ref1, ref2):
-            return self._attend_general_hip(feat1, feat2, P1, P2, camera, other_camera)
+            return self._attend_general_hip(feat1, feat2, P1, P2, camera, other_camera, ref1, ref2)
         N, C, H, W = feat2.shape
         per_pair = 2 * self.sample_size * max(C, feat1.shape[1]) * H * W * 4 * (2 if torch.is_grad_enabled() else 1)
         step = max(1, int(amd_knob(self.cfg, "GENERAL_MODE_BYTES", 2 << 30)) // per_pair)
@@ -122,44 +122,55 @@ class Epipolar(nn.Module):
         return tuple(torch.cat([p[i] for p in parts]) for i in range(3))
 
     def _general_kernel_applies(self, feat1, feat2, ref1=None, ref2=None) -> bool:
-        """True when the HIP general kernels compute this call: ATTENTION avg over a dot-product similarity of feature maps
-        (theta / phi / g, BOTTLENECK, POOLING in any combination; PRIOR / PRIORMUL too, but only when nothing asks for a
-        gradient -- `et_epipolar_backward_general` has no prior term, training with a prior takes the chunked torch
-        restatement below)."""
+        """True when the HIP general kernels compute this call.  Forward (`et_epipolar_forward_general`): every branch of
+        a12 / N4 -- theta / phi / g, BOTTLENECK, POOLING, PRIOR / PRIORMUL, SIMILARITY cos, ATTENTION max, FIND_CORR rgb --
+        except SIMILARITY prior.  With a gradient requested (`et_epipolar_backward_general`, through ops.GeneralAttend):
+        the dot-product branches without a prior; the others then take the chunked torch restatement below."""
         e = self.cfg.EPIPOLAR
-        if not (e.ATTENTION == "avg" and e.SIMILARITY == "dot" and e.FIND_CORR == "feature" and ref1 is None and ref2 is None):
+        if e.ATTENTION not in ("avg", "max") or (e.ATTENTION == "avg" and e.SIMILARITY not in ("dot", "cos")):
             return False
-        if not bool(amd_knob(self.cfg, "GENERAL_KERNEL", True)) or not feat1.is_cuda:
+        if e.FIND_CORR == "rgb" and (ref1 is None or ref2 is None):
+            return False
+        if not bool(amd_knob(self.cfg, "GENERAL_KERNEL", True)) or not feat2.is_cuda:
             return False
         if e.POOLING and self.sample_size % 2:
             return False
-        if e.PRIOR and torch.is_grad_enabled():
+        if (e.PRIOR or e.ATTENTION == "max" or e.SIMILARITY == "cos") and torch.is_grad_enabled():
             params = [q for k in ("theta", "phi", "g") if k in e.PARAMETERIZED for q in getattr(self, k).parameters()]
-            params += list(self.prior.values())
+            params += list(self.prior.values()) if e.PRIOR else []
             if feat1.requires_grad or feat2.requires_grad or any(q.requires_grad for q in params):
                 return False
-        c_sim = feat1.shape[1] // (e.BOTTLENECK if "theta" in e.PARAMETERIZED else 1)
+        c_sim = 3 if e.FIND_CORR == "rgb" else feat1.shape[1] // (e.BOTTLENECK if "theta" in e.PARAMETERIZED else 1)
         return c_sim <= 512
 
-    def _attend_general_hip(self, feat1, feat2, P1, P2, camera=None, other_camera=None):
-        """The parameterised / pooled / prior branches through the HIP general kernels: the 1x1 convolutions act on the
-        maps (epipolar.py:138-153: torch / MIOpen GEMMs, with autograd), the kernel samples, pools, masks, soft-maxes and
-        sums without materialising a K x C x H x W tensor (`ops.GeneralAttend`; with a prior `ops.forward_general_nhwc`,
-        forward only)."""
+    def _attend_general_hip(self, feat1, feat2, P1, P2, camera=None, other_camera=None, ref1=None, ref2=None):
+        """The non-headline branches through the HIP general kernels: the 1x1 convolutions act on the maps
+        (epipolar.py:138-153: torch / MIOpen GEMMs, with autograd), the kernel samples, pools, masks, soft-maxes and sums
+        without materialising a K x C x H x W tensor (`ops.GeneralAttend`; prior / cosine / ATTENTION max:
+        `ops.forward_general_nhwc`, forward only)."""
         e = self.cfg.EPIPOLAR
-        other1 = feat2 if "other1" in e.OTHER_GRAD else feat2.detach()                  # :138-141
+        if e.FIND_CORR == "rgb":                                                        # :131-136
+            assert "other1" not in e.OTHER_GRAD and "phi" not in e.PARAMETERIZED
+            m1, q = ref2.detach(), ref1
+        else:
+            other1 = feat2 if "other1" in e.OTHER_GRAD else feat2.detach()              # :138-141
+            m1 = self.phi(other1) if "phi" in e.PARAMETERIZED else other1               # :142-143
+            q = self.theta(feat1) if "theta" in e.PARAMETERIZED else feat1              # :144-145
         other2 = feat2 if "other2" in e.OTHER_GRAD else feat2.detach()                  # :147-150
-        q = self.theta(feat1) if "theta" in e.PARAMETERIZED else feat1                  # :144-145
-        m1 = self.phi(other1) if "phi" in e.PARAMETERIZED else other1                   # :142-143
         m2 = self.g(other2) if "g" in e.PARAMETERIZED else other2                       # :152-153
         with torch.no_grad():
             cam = self._cam(P1, P2, feat2.device)
-        if not e.PRIOR:
+        is_max, cos = e.ATTENTION == "max", e.ATTENTION == "avg" and e.SIMILARITY == "cos"
+        if not (e.PRIOR or is_max or cos):
             return ops.GeneralAttend.apply(q, m1, m2, cam, self.layer_spec(), bool(e.POOLING))
         with torch.no_grad():                                                           # :288-289, :300-301, :308-309
-            prior = torch.stack([self.prior[(int(a), int(b))].to(q) for a, b in zip(camera, other_camera)]).contiguous()
+            prior = None
+            if e.PRIOR and not is_max:
+                prior = torch.stack([self.prior[(int(a), int(b))].to(q) for a, b in zip(camera, other_camera)]).contiguous()
             out, attn, corr_pos = ops.forward_general_nhwc(self.layer_spec(), ops.to_nhwc(q), ops.to_nhwc(m1), ops.to_nhwc(m2),
-                                                           cam, prior=prior, pooling=bool(e.POOLING), prior_mul=bool(e.PRIORMUL))
+                                                           cam, prior=prior, pooling=bool(e.POOLING),
+                                                           prior_mul=bool(prior is not None and e.PRIORMUL), cosine=cos,
+                                                           attention_max=is_max)
         return out.permute(0, 3, 1, 2), attn, corr_pos
 
     def _attend_general_chunk(self, feat1, feat2, P1, P2, camera=None, other_camera=None, ref1=None, ref2=None):

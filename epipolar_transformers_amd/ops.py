@@ -121,7 +121,8 @@ def sample_locs(spec: LayerSpec, cam: torch.Tensor) -> torch.Tensor:
 
 
 def forward_general_nhwc(spec: LayerSpec, q: torch.Tensor, map_sim: torch.Tensor, map_val: torch.Tensor, cam: torch.Tensor,
-                         prior: torch.Tensor = None, pooling=False, prior_mul=False, want_attn=True, want_corr=True):
+                         prior: torch.Tensor = None, pooling=False, prior_mul=False, cosine=False, attention_max=False,
+                         want_attn=True, want_corr=True):
     """The operator's parameterised / pooled / prior branches as ONE kernel (et_epipolar_forward_general; forward only).
     q, map_sim: (N,H,W,Cs); map_val: (N,H,W,Cv), channels last, contiguous; prior: (N,K',H,W) or None, K' = K/2 with
     `pooling` (epipolar.py:200-202), else K.  Returns out (N,H,W,Cv), attn (N,K',H,W)|None, corr_pos (N,H,W,2)|None."""
@@ -145,7 +146,8 @@ def forward_general_nhwc(spec: LayerSpec, q: torch.Tensor, map_sim: torch.Tensor
     out = torch.empty((n, h, w, cv), dtype=torch.float32, device=q.device)
     attn = torch.empty((n, ks, h, w), dtype=torch.float32, device=q.device) if want_attn else None
     corr = torch.empty((n, h, w, 2), dtype=torch.float32, device=q.device) if want_corr else None
-    flags = (_lib.ET_GENERAL_POOLING if pooling else 0) | (_lib.ET_GENERAL_PRIOR_MUL if prior_mul else 0)
+    flags = ((_lib.ET_GENERAL_POOLING if pooling else 0) | (_lib.ET_GENERAL_PRIOR_MUL if prior_mul else 0) |
+             (_lib.ET_GENERAL_COSINE if cosine else 0) | (_lib.ET_GENERAL_ATTENTION_MAX if attention_max else 0))
     d = spec.desc(n, 4)
     with torch.cuda.device(q.device):
         _lib.check(_lib.load().et_epipolar_forward_general(

@@ -164,10 +164,13 @@ int et_epipolar_forward_tiled(const EtLayerDesc *desc, const float *xs, const fl
  *   out      : (N,H,W,c_val)  sum_k' attn_k' * (pooled) sample_k' of map_val   (epipolar.py:243)
  *   attn     nullable : (N,K',H,W);  corr_pos nullable : (N,H,W,2), the location of sample arg-max_k' attn of the
  *              unpooled list (epipolar.py:237-242).
- * ATTENTION avg, SIMILARITY dot, FIND_CORR feature; soft-max on or off as `desc` says; desc->C is ignored
+ * ATTENTION avg | max, SIMILARITY dot | cos; FIND_CORR rgb is q = ref1, map_sim = ref2 (3 channels); soft-max on or off
+ * as `desc` says; desc->C is ignored
  * (c_sim <= 512, c_val <= 4096, any positive value).  Nothing of size K x C x H x W is materialised. */
 #define ET_GENERAL_POOLING 1
 #define ET_GENERAL_PRIOR_MUL 2
+#define ET_GENERAL_COSINE 4          /* SIMILARITY cos: F.cosine_similarity(q, sample) (epipolar.py:290-293), then mask / prior / soft-max as for dot */
+#define ET_GENERAL_ATTENTION_MAX 8   /* ATTENTION max (epipolar.py:282-286, 222-235): attn = the raw cosine similarity, out = the arg-max sample of map_val; no prior */
 int et_epipolar_forward_general(const EtLayerDesc *desc, const float *xs, const float *ys, const float *steps,
                                 const float *cam, const float *q, const float *map_sim, const float *map_val,
                                 const float *prior, int c_sim, int c_val, int flags, float *out, float *attn,

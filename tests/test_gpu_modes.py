@@ -154,36 +154,43 @@ def test_debug_mode_returns_the_reference_nine_tuple():
 
 
 # ---- the parameterised / pooled / prior branches as ONE HIP kernel (et_epipolar_forward_general, forward only) ----------
-GENERAL_KERNEL_MODES = [m for m in MODES if m.startswith(("param_pool", "prior_add", "prior_mul"))]
+GENERAL_KERNEL_MODES = MODES          # every fixture's branch has a forward on the general kernel
 
 
 @pytest.mark.parametrize("name", GENERAL_KERNEL_MODES)
 def test_general_kernel_vs_reference(name):
     """No gradient requested -> the module takes `et_epipolar_forward_general`; its outputs against the REAL reference's
-    (theta / phi / g with BOTTLENECK 2 + POOLING; PRIOR added; PRIOR multiplied)."""
+    (theta / phi / g with BOTTLENECK 2 + POOLING; PRIOR added / multiplied; cosine similarity; ATTENTION max; FIND_CORR rgb)."""
     d = np.load(os.path.join(GOLDEN_DIR, "modes", name + ".npz"))
     mod = _module(d)
     dev = lambda k: torch.from_numpy(d[k]).cuda()
     f1, f2 = dev("feat1"), dev("feat2")
+    kw = dict(camera=torch.from_numpy(d["camera"]), other_camera=torch.from_numpy(d["other_camera"]))
+    if "rgb" in name:
+        kw.update(ref1=dev("rgb1"), ref2=dev("rgb2"))
     with torch.no_grad():
-        assert mod._general_kernel_applies(f1, f2)
+        assert mod._general_kernel_applies(f1, f2, kw.get("ref1"), kw.get("ref2"))
     called = []
     from epipolar_transformers_amd import ops
     real = ops.forward_general_nhwc
     ops.forward_general_nhwc = lambda *a, **k: (called.append(1), real(*a, **k))[1]
     try:
         with torch.no_grad():
-            fin, corr, depth, _ = mod(f1, f2, torch.from_numpy(d["P1"]), torch.from_numpy(d["P2"]),
-                                      camera=torch.from_numpy(d["camera"]), other_camera=torch.from_numpy(d["other_camera"]))
+            fin, corr, depth, _ = mod(f1, f2, torch.from_numpy(d["P1"]), torch.from_numpy(d["P2"]), **kw)
     finally:
         ops.forward_general_nhwc = real
     assert called, "the HIP general kernel did not run"
     assert tuple(fin.shape) == d["finalout"].shape and tuple(depth.shape) == d["depth"].shape
     locs = ops.sample_locs(mod.layer_spec(), torch.from_numpy(d["cam"]).cuda()).cpu().numpy()
     depth_np = depth.cpu().numpy()
-    assert_corr_pos(locs, corr.cpu().numpy(), d["corr_pos"], depth_np, True, tie=2e-6, max_frac=2e-2)
+    ties = assert_corr_pos(locs, corr.cpu().numpy(), d["corr_pos"], depth_np, True, tie=2e-6, max_frac=2e-2)
     assert np.abs(depth_np - d["depth"]).max() <= 1e-5 * max(1.0, float(np.abs(d["depth"]).max()))
-    assert np.abs(fin.cpu().numpy() - d["finalout"]).max() <= 1e-4 * max(1.0, float(np.abs(d["finalout"]).max()))
+    err = np.abs(fin.cpu().numpy() - d["finalout"])
+    tol = 1e-4 * max(1.0, float(np.abs(d["finalout"]).max()))
+    if "attention_max" in name:        # (a proven arg-max tie gathers the other, equally good sample: exempt, as above)
+        assert (err.max(1) <= tol)[~ties].all()
+    else:
+        assert err.max() <= tol
 
 
 @pytest.mark.parametrize("case", [
@@ -191,6 +198,8 @@ def test_general_kernel_vs_reference(name):
     dict(H=24, C=64, K=33, N=3, bottleneck=1, pooling=False, prior=True, softmax=True),      # ragged K, prior added
     dict(H=16, C=32, K=130, N=2, bottleneck=4, pooling=True, prior=True, priormul=True, softmax=True),   # K' = 65 > one wave
     dict(H=16, C=16, K=12, N=2, bottleneck=1, pooling=True, prior=False, softmax=False),     # soft-max off: sim / K'
+    dict(H=24, C=32, K=20, N=3, bottleneck=2, pooling=True, prior=True, softmax=True, similarity="cos"),
+    dict(H=24, C=32, K=20, N=3, bottleneck=1, pooling=False, prior=False, softmax=True, attention="max"),
 ])
 def test_general_kernel_vs_torch_restatement(case):
     """The HIP kernel against the chunked torch restatement of the same branches (itself pinned to the reference fixtures
@@ -203,7 +212,8 @@ def test_general_kernel_vs_torch_restatement(case):
     cfg = default_cfg()
     cfg.merge_from_list(["KEYPOINT.HEATMAP_SIZE", (H, H), "KEYPOINT.NFEATS", C, "EPIPOLAR.SAMPLESIZE", K,
                          "DATASETS.IMAGE_SIZE", (4 * H, 4 * H), "EPIPOLAR.USE_CORRECT_NORMALIZE", True,
-                         "EPIPOLAR.ATTENTION", "avg", "EPIPOLAR.PARAMETERIZED", par, "EPIPOLAR.BOTTLENECK", case["bottleneck"],
+                         "EPIPOLAR.ATTENTION", case.get("attention", "avg"), "EPIPOLAR.SIMILARITY", case.get("similarity", "dot"),
+                         "EPIPOLAR.PARAMETERIZED", par, "EPIPOLAR.BOTTLENECK", case["bottleneck"],
                          "EPIPOLAR.ZRESIDUAL", case["bottleneck"] == 1, "EPIPOLAR.POOLING", case["pooling"],
                          "EPIPOLAR.PRIOR", case["prior"], "EPIPOLAR.PRIORMUL", bool(case.get("priormul")),
                          "EPIPOLAR.SOFTMAX_ENABLED", case["softmax"], "DATASETS.CAMERAS", (0, 1, 2, 3)])
@@ -230,10 +240,11 @@ def test_general_kernel_vs_torch_restatement(case):
         out_t, attn_t, corr_t = mod._attend_general_chunk(f1, f2, P1, P2, cams[0], cams[1])
     assert attn_h.shape == attn_t.shape and out_h.shape == out_t.shape
     assert (attn_h - attn_t).abs().max().item() <= 1e-5 * max(1.0, attn_t.abs().max().item())
-    assert (out_h - out_t).abs().max().item() <= 1e-4 * max(1.0, out_t.abs().max().item())
     from epipolar_transformers_amd import ops
     locs = ops.sample_locs(mod.layer_spec(), mod._cam(P1, P2, f1.device)).cpu().numpy()
-    assert_corr_pos(locs, corr_h.cpu().numpy(), corr_t.cpu().numpy(), attn_h.cpu().numpy(), True, tie=2e-6, max_frac=2e-2)
+    ties = assert_corr_pos(locs, corr_h.cpu().numpy(), corr_t.cpu().numpy(), attn_h.cpu().numpy(), True, tie=2e-6, max_frac=2e-2)
+    ok = (out_h - out_t).abs().amax(1) <= 1e-4 * max(1.0, out_t.abs().max().item())          # (N,H,W)
+    assert ok.all() if case.get("attention") != "max" else ok[~torch.from_numpy(ties).cuda()].all()
 
 
 def test_general_kernel_routing():
