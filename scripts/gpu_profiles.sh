@@ -14,11 +14,11 @@ stats() {  # stats NAME -- bench args...   : rocprofv3 --kernel-trace --stats of
   [ -n "$f" ] && cp "$f" "$OUT/${TAG}_${name}_kernel_stats.csv" && head -6 "$f"
   rm -rf "$OUT/prof_${TAG}_$name"
 }
-echo "== bench (configs[1])"; timeout 900 python bench.py --steps 30 --warmup 5 --end-to-end > "$OUT/${TAG}_bench.json" 2> "$OUT/${TAG}_bench.err"; tail -c 600 "$OUT/${TAG}_bench.json"; echo
-echo "== bench classic (exact fp32 one-block-per-tile kernel)"; timeout 600 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --variant 65536 > "$OUT/${TAG}_bench_variant65536_classic_fp32.json" 2>> "$OUT/${TAG}_bench.err"
-echo "== bench per-pixel"; timeout 600 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --variant 16384 > "$OUT/${TAG}_bench_variant16384_perpixel.json" 2>> "$OUT/${TAG}_bench.err"
-echo "== bench config4 head (96x96, K=64, 128 pairs)"; timeout 600 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --hw 96 > "$OUT/${TAG}_bench_config4.json" 2>> "$OUT/${TAG}_bench.err"
-echo "== bench config5 share (128x128, K=128, 8 views x 8 frames = 64 pairs)"; timeout 600 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --samples 128 --hw 128 --frames 8 --views 8 > "$OUT/${TAG}_bench_config5.json" 2>> "$OUT/${TAG}_bench.err"
+echo "== bench (configs[1])"; timeout 900 python bench.py --steps 30 --warmup 5 > "$OUT/${TAG}_bench.json" 2> "$OUT/${TAG}_bench.err"; tail -c 600 "$OUT/${TAG}_bench.json"; echo
+echo "== bench classic (exact fp32 one-block-per-tile kernel)"; timeout 600 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-end-to-end --variant 65536 > "$OUT/${TAG}_bench_variant65536_classic_fp32.json" 2>> "$OUT/${TAG}_bench.err"
+echo "== bench per-pixel"; timeout 600 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-end-to-end --variant 16384 > "$OUT/${TAG}_bench_variant16384_perpixel.json" 2>> "$OUT/${TAG}_bench.err"
+echo "== bench config4 head (96x96, K=64, 128 pairs)"; timeout 600 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-end-to-end --hw 96 > "$OUT/${TAG}_bench_config4.json" 2>> "$OUT/${TAG}_bench.err"
+echo "== bench config5 share (128x128, K=128, 8 views x 8 frames = 64 pairs)"; timeout 600 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-end-to-end --samples 128 --hw 128 --frames 8 --views 8 > "$OUT/${TAG}_bench_config5.json" 2>> "$OUT/${TAG}_bench.err"
 python - <<PY
 import json
 for n in ("bench", "bench_variant65536_classic_fp32", "bench_variant16384_perpixel", "bench_config4", "bench_config5"):
@@ -49,7 +49,8 @@ PY
 f=$(find "$OUT/prof_${TAG}_epi" -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" "$OUT/${TAG}_epilogue_kernel_stats.csv" && head -4 "$f"; rm -rf "$OUT/prof_${TAG}_epi"
 echo "== PMC forward"; bash scripts/gpu_pmc.sh "${TAG}_fwd_tile" 0 fwd | tail -34
 echo "== PMC backward"; bash scripts/gpu_pmc.sh "${TAG}_bwd_tile" 0 bwd | tail -34
+echo "== parameterised + pooled head through the general kernel"; timeout 300 python scripts/general_mode_time.py 2>/dev/null | tail -1 | tee "$OUT/${TAG}_general_mode_time.txt"
 echo "== microbenchmarks"
-for m in mfma_valu_overlap mfma_valu_samewave load_patterns; do
+for m in mfma_valu_overlap mfma_valu_samewave load_patterns mfma_lds_rates; do
   [ -x scripts/micro/$m ] && timeout 120 scripts/micro/$m > "$OUT/${TAG}_micro_$m.txt" 2>&1 && tail -3 "$OUT/${TAG}_micro_$m.txt"
 done
