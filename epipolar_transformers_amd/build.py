@@ -22,7 +22,8 @@ COMMON = ["et_common.h", "epipolar_geometry.h", os.path.join(ROOT, "include", "e
 UNITS = {
     "et_forward.hip": ["kernels_sample_table.inc", "kernels_forward.inc"],
     "et_forward_general.hip": ["et_wave_reduce.h"],
-    "et_forward_tile.hip": ["kernels_forward_tile.inc", "kernels_forward_tile_ws.inc", "et_tile_host.h", "et_wave_reduce.h", "et_split_f16.h"],
+    "et_forward_tile.hip": ["kernels_forward_tile.inc", "kernels_forward_tile_ws.inc", "kernels_source_planes.inc",
+                            "kernels_forward_tile_ws2.inc", "et_tile_host.h", "et_wave_reduce.h", "et_split_f16.h"],
     "et_backward.hip": ["kernels_sample_table.inc", "kernels_backward.inc"],
     "et_backward_tile.hip": ["kernels_forward_tile.inc", "kernels_backward_tile.inc", "et_tile_host.h", "et_wave_reduce.h", "et_split_f16.h"],
     "et_misc.hip": ["kernels_misc.inc"],
@@ -48,6 +49,11 @@ def hipcc() -> str:
 
 
 _EXTRA = []      # extra defines of a development build (build_profile_library)
+# Per-unit flags.  et_forward_tile.hip is compiled WITHOUT SLP vectorisation: with it the tap arithmetic of the
+# one-block-per-tile kernel becomes packed-fp32 instructions (v_pk_add_f32 / v_pk_mul_f32 with op_sel), and the kernel then
+# returned wrong attention in lanes 48-63 of single pixels whenever blocks running its split-fp16 GEMM shared a SIMD with
+# blocks in the soft-max phase -- 20 of 20 runs with SLP, 0 of 20 without, nothing else changed (scripts/dev/README.md).
+_UNIT_FLAGS = {"et_forward_tile.hip": ["-fno-slp-vectorize"]}
 
 
 def flags():
@@ -73,7 +79,7 @@ def needs_build() -> bool:
 
 
 def _compile(unit, report):
-    cmd = [hipcc()] + flags() + (["-Rpass-analysis=kernel-resource-usage"] if report else []) + \
+    cmd = [hipcc()] + flags() + _UNIT_FLAGS.get(unit, []) + (["-Rpass-analysis=kernel-resource-usage"] if report else []) + \
         ["-c", "-o", _obj(unit), _path(unit)]
     proc = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     return unit, proc.returncode, proc.stdout

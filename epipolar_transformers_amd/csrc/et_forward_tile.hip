@@ -88,14 +88,16 @@ int et_epipolar_forward_tiled(const EtLayerDesc *desc, const float *xs, const fl
     const size_t lds_sort = (size_t)n2 * sizeof(unsigned long long);
     const int dev = current_device();
     ET_GRANT_LDS(tile_order_kernel, lds_sort, dev);
-    // (the per-pair scale estimates only for the first-generation kernel; the second scales every row exactly)
-    float *scales = tile_ws_eligible(desc) && !tile_ws2_eligible(desc) ? w.scales : nullptr;
+    // (per-pair scale estimates of the source maps: for the split-fp16 GEMMs of the first-generation persistent kernel and
+    //  of the one-block-per-tile kernel; ET_VARIANT_TILE_EXACT keeps the latter in exact fp32)
+    float *scales = w.scales;
+    tp.scales = (desc->variant & ET_VARIANT_TILE_EXACT) ? nullptr : w.scales;
     hipLaunchKernelGGL(tile_order_kernel, dim3(desc->N), dim3(1024), lds_sort, st, *desc, xs, ys, cam, n2,
                        tp.tiles_per_pair * kTilePix, w.perm, w.ovf_count, feat_ref, feat_src, scales, w.segs);
     if (int e = check_launch("et_epipolar_forward_tiled(order)")) return e;
     const int kpl = (desc->K + 63) / 64;
     const int rows = tile_rows(desc);
-    const size_t lds = (size_t)(tile_array_floats(rows) + rows + kTilePix + 4 + kTilePix * 4) * 4 +
+    const size_t lds = (size_t)(fwd_tile_array_floats(rows) + rows + kTilePix + 48 + kTilePix * 4) * 4 +
                        (size_t)tp.hw_words * 8 + (kpl == 1 ? (size_t)kTilePix * kWave * 8 : 0);
 #define ET_SET_LDS(KERNEL, BYTES) ET_GRANT_LDS(KERNEL, BYTES, dev)
     if (tile_ws2_eligible(desc)) {

@@ -77,6 +77,19 @@ def _stream(t: torch.Tensor):
     return ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
 
 
+POISON_OUTPUTS = False      # tests set this: every output buffer starts as NaN, so that a kernel that leaves part of its
+                            # output unwritten cannot hide behind the (correct) values a recycled allocation still holds
+
+
+def _empty(shape, like=None, device=None, dtype=torch.float32):
+    if like is not None:
+        shape, device, dtype = like.shape, like.device, like.dtype
+    t = torch.empty(tuple(shape), dtype=dtype, device=device)
+    if POISON_OUTPUTS and t.is_floating_point():
+        t.fill_(float("nan"))
+    return t
+
+
 def _ptr(t):
     return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
 
@@ -90,7 +103,7 @@ def to_nhwc(x: torch.Tensor) -> torch.Tensor:
     if perm.is_contiguous():
         return perm
     src = x.contiguous()
-    dst = torch.empty((n, h, w, c), dtype=x.dtype, device=x.device)
+    dst = _empty((n, h, w, c), device=x.device, dtype=x.dtype)
     with torch.cuda.device(x.device):
         _lib.check(_lib.load().et_nchw_to_nhwc(n, c, h, w, _ptr(src), _ptr(dst), _stream(x)), "et_nchw_to_nhwc")
     return dst
@@ -100,7 +113,7 @@ def to_nchw_contiguous(x_nhwc: torch.Tensor) -> torch.Tensor:
     """(N,H,W,C) memory -> NCHW-contiguous tensor via et_nhwc_to_nchw."""
     _require_gpu(x_nhwc, "feature map")
     n, h, w, c = x_nhwc.shape
-    dst = torch.empty((n, c, h, w), dtype=x_nhwc.dtype, device=x_nhwc.device)
+    dst = _empty((n, c, h, w), device=x_nhwc.device, dtype=x_nhwc.dtype)
     with torch.cuda.device(x_nhwc.device):
         _lib.check(_lib.load().et_nhwc_to_nchw(n, c, h, w, _ptr(x_nhwc.contiguous()), _ptr(dst), _stream(x_nhwc)),
                    "et_nhwc_to_nchw")
@@ -112,7 +125,7 @@ def sample_locs(spec: LayerSpec, cam: torch.Tensor) -> torch.Tensor:
     _require_gpu(cam, "cam")
     n = cam.shape[0]
     xs, ys, steps = spec.constants(cam.device)
-    out = torch.empty((spec.K, n, spec.H, spec.W, 2), dtype=torch.float32, device=cam.device)
+    out = _empty((spec.K, n, spec.H, spec.W, 2), device=cam.device)
     d = spec.desc(n, 4)
     with torch.cuda.device(cam.device):
         _lib.check(_lib.load().et_sample_locs(ctypes.byref(d), _ptr(xs), _ptr(ys), _ptr(steps), _ptr(cam), _ptr(out),
@@ -143,9 +156,9 @@ def forward_general_nhwc(spec: LayerSpec, q: torch.Tensor, map_sim: torch.Tensor
         if tuple(prior.shape) != (n, ks, h, w) or not prior.is_contiguous():
             raise ValueError("prior must be (N,K',H,W) = %s, got %s" % ((n, ks, h, w), tuple(prior.shape)))
     xs, ys, steps = spec.constants(q.device)
-    out = torch.empty((n, h, w, cv), dtype=torch.float32, device=q.device)
-    attn = torch.empty((n, ks, h, w), dtype=torch.float32, device=q.device) if want_attn else None
-    corr = torch.empty((n, h, w, 2), dtype=torch.float32, device=q.device) if want_corr else None
+    out = _empty((n, h, w, cv), device=q.device)
+    attn = _empty((n, ks, h, w), device=q.device) if want_attn else None
+    corr = _empty((n, h, w, 2), device=q.device) if want_corr else None
     flags = ((_lib.ET_GENERAL_POOLING if pooling else 0) | (_lib.ET_GENERAL_PRIOR_MUL if prior_mul else 0) |
              (_lib.ET_GENERAL_COSINE if cosine else 0) | (_lib.ET_GENERAL_ATTENTION_MAX if attention_max else 0))
     d = spec.desc(n, 4)
@@ -169,7 +182,7 @@ def backward_general_nhwc(spec: LayerSpec, q, map_sim, map_val, cam, grad_out, p
     if not (q.is_contiguous() and map_sim.is_contiguous() and map_val.is_contiguous()):
         raise ValueError("q / map_sim / map_val must be contiguous (N,H,W,C) tensors")
     xs, ys, steps = spec.constants(q.device)
-    gq = torch.empty_like(q)
+    gq = _empty(None, like=q)
     gsim = torch.zeros_like(map_sim) if need_sim else None
     gval = torch.zeros_like(map_val) if need_val else None
     d = spec.desc(n, 4)
@@ -204,7 +217,7 @@ class GeneralAttend(torch.autograd.Function):
 
 
 _TILE_BITS = (_lib.ET_VARIANT_TILE_SPLIT | _lib.ET_VARIANT_TILE_CLASSIC | _lib.ET_VARIANT_WS_V2 |
-              _lib.ET_VARIANT_WS_SETPRIO)      # variant bits that tune the tile path instead of leaving it
+              _lib.ET_VARIANT_WS_SETPRIO | _lib.ET_VARIANT_TILE_EXACT)      # variant bits that tune the tile path instead of leaving it
 
 
 def forward_nhwc(spec: LayerSpec, ref: torch.Tensor, src: torch.Tensor, cam: torch.Tensor,
@@ -222,10 +235,10 @@ def forward_nhwc(spec: LayerSpec, ref: torch.Tensor, src: torch.Tensor, cam: tor
         raise ValueError("cam must be a contiguous (N,%d) tensor" % _lib.ET_CAM_STRIDE)
     assert ref.is_contiguous() and src.is_contiguous()
     xs, ys, steps = spec.constants(ref.device)
-    out = torch.empty_like(ref)
-    attn = torch.empty((n, spec.K, h, w), dtype=torch.float32, device=ref.device) if want_attn else None
-    corr = torch.empty((n, h, w, 2), dtype=torch.float32, device=ref.device) if want_corr else None
-    base = torch.empty_like(ref) if want_res_base else None
+    out = _empty(None, like=ref)
+    attn = _empty((n, spec.K, h, w), device=ref.device) if want_attn else None
+    corr = _empty((n, h, w, 2), device=ref.device) if want_corr else None
+    base = _empty(None, like=ref) if want_res_base else None
     if res_bias is not None:
         assert want_res_base and res_bias.is_cuda and res_bias.numel() == c and res_bias.is_contiguous()
     d = spec.desc(n, c)
@@ -339,8 +352,8 @@ def backward_nhwc(spec: LayerSpec, ref, src, cam, grad_out, use_workspace=True, 
     n, h, w, c = ref.shape
     xs, ys, steps = spec.constants(ref.device)
     grad_out = grad_out.contiguous()
-    g_ref = torch.empty_like(ref)
-    g_src = torch.empty_like(src)
+    g_ref = _empty(None, like=ref)
+    g_src = _empty(None, like=src)
     d = spec.desc(n, c)
     lib = _lib.load()
     tile_bytes = int(lib.et_epipolar_backward_tiled_workspace_bytes(ctypes.byref(d)))
@@ -375,8 +388,8 @@ def backward_nhwc(spec: LayerSpec, ref, src, cam, grad_out, use_workspace=True, 
 def residual_epilogue(feat, out, y=None, scale=None, shift=None, want_finalout=True, want_x=True):
     """All (N,H,W,C) contiguous.  finalout = out + y*scale + shift ; x = feat + finalout."""
     n, h, w, c = out.shape
-    fin = torch.empty_like(out) if want_finalout else None
-    x = torch.empty_like(out) if want_x else None
+    fin = _empty(None, like=out) if want_finalout else None
+    x = _empty(None, like=out) if want_x else None
     with torch.cuda.device(out.device):
         _lib.check(_lib.load().et_residual_epilogue(n * h * w, c, _ptr(feat), _ptr(out), _ptr(y), _ptr(scale),
                                                     _ptr(shift), _ptr(fin), _ptr(x), _stream(out)),
@@ -404,7 +417,7 @@ def residual_gemm(out: torch.Tensor, packed: torch.Tensor, bias: torch.Tensor, f
     c = out.shape[-1]
     assert out.is_contiguous() and (feat is None or (feat.is_contiguous() and feat.shape == out.shape))
     assert bias.is_cuda and bias.numel() == c and bias.is_contiguous()
-    x = torch.empty_like(out)
+    x = _empty(None, like=out)
     with torch.cuda.device(out.device):
         _lib.check(_lib.load().et_residual_gemm(out.numel() // c, c, _ptr(out), _ptr(feat), _ptr(packed), _ptr(bias), _ptr(x),
                                                 _stream(out)), "et_residual_gemm")
@@ -418,8 +431,8 @@ def heatmap_peaks(heatmaps: torch.Tensor, radius: float, downsample: float, thre
     _require_gpu(heatmaps, "heatmaps")
     n, j, h, w = heatmaps.shape
     hm = heatmaps.detach().contiguous()
-    locs = torch.empty((n, j, 2), dtype=torch.float32, device=hm.device)
-    scores = torch.empty((n, j), dtype=torch.float32, device=hm.device)
+    locs = _empty((n, j, 2), device=hm.device)
+    scores = _empty((n, j), device=hm.device)
     with torch.cuda.device(hm.device):
         _lib.check(_lib.load().et_heatmap_peaks(n * j, h, w, _ptr(hm), float(radius), float(downsample), float(threshold),
                                                 int(bool(legacy_floor_division)), _ptr(locs), _ptr(scores), _stream(hm)),

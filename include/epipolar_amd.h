@@ -78,9 +78,10 @@ typedef struct EtLayerDesc {
 #define ET_VARIANT_BWD_UNSORTED 8192 /* backward gather: sum in arrival order (faster, not bit-reproducible) */
 #define ET_VARIANT_NO_TILE 16384  /* host wrappers: do not route C == 256 calls to et_epipolar_forward_tiled */
 #define ET_VARIANT_TILE_SPLIT 32768 /* et_epipolar_forward_tiled, testing: 64-row tiles, so that tiles overflow and split */
-#define ET_VARIANT_TILE_CLASSIC 65536 /* et_epipolar_forward_tiled: the one-block-per-tile kernel (exact fp32) instead of the warp-specialised persistent one */
+#define ET_VARIANT_TILE_CLASSIC 65536 /* et_epipolar_forward_tiled: the one-block-per-tile kernel (split-fp16 GEMMs, exact-fp32 redo of overflowing tiles) instead of the warp-specialised persistent one */
 #define ET_VARIANT_WS_V2 131072   /* et_epipolar_forward_tiled: the second-generation warp-specialised kernel (source maps pre-split into fp16 planes under exact per-row scales; kernels_forward_tile_ws2.inc) instead of the first */
 #define ET_VARIANT_WS_SETPRIO 262144 /* warp-specialised kernel (first generation), tuning: s_setprio 1 on the matrix waves */
+#define ET_VARIANT_TILE_EXACT 524288 /* et_epipolar_forward_tiled, one-block-per-tile kernel: both GEMMs in exact fp32 (v_mfma_f32_32x32x2_f32) instead of split-fp16 products */
 #define ET_VARIANT_BASELINE 256    /* batches of 8, compiler-chosen registers, pixels 4w..4w+3 per wave   */
 /* Bits 64 and 128 are reserved: in development builds of the library (-DET_DEV_ABLATE) they switch the per-pixel
  * kernel's tap loads off for roofline ablations (wrong results by construction); a product build rejects them. */
