@@ -53,7 +53,9 @@ _EXTRA = []      # extra defines of a development build (build_profile_library)
 # one-block-per-tile kernel becomes packed-fp32 instructions (v_pk_add_f32 / v_pk_mul_f32 with op_sel), and the kernel then
 # returned wrong attention in lanes 48-63 of single pixels whenever blocks running its split-fp16 GEMM shared a SIMD with
 # blocks in the soft-max phase -- 20 of 20 runs with SLP, 0 of 20 without, nothing else changed (scripts/dev/README.md).
-_UNIT_FLAGS = {"et_forward_tile.hip": ["-fno-slp-vectorize"]}
+# The backward tile kernel has the same phase structure (split-fp16 GEMM, then per-sample tap arithmetic, two blocks per CU);
+# it never showed the fault, and the flag costs it nothing (2.45 vs 2.47 ms), so it is built the same way.
+_UNIT_FLAGS = {"et_forward_tile.hip": ["-fno-slp-vectorize"], "et_backward_tile.hip": ["-fno-slp-vectorize"]}
 
 
 def flags():

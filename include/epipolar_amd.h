@@ -127,7 +127,9 @@ int et_epipolar_forward(const EtLayerDesc *desc, const float *xs, const float *y
  * workspace), then one persistent block per compute unit whose waves are specialised (matrix waves run
  * the two GEMMs of consecutive tiles back to back as fp16 MFMAs with fp32 accumulation, ~22
  * significant bits per product; vector waves do the geometry / soft-max work of the neighbouring tiles
- * meanwhile).  Other shapes run one block per tile in exact fp32.  Same arguments and results as
+ * meanwhile).  Other shapes (maps above 64 x 64, K > 64) run one block per tile with the same split-fp16
+ * GEMMs; a tile with a value beyond fp16's range, and every call with the soft-max off, is computed in
+ * exact fp32 (ET_VARIANT_TILE_EXACT: always).  Same arguments and results as
  * et_epipolar_forward (rounding differs at the 1e-6 level: the sums are re-associated), plus
  *   workspace : device scratch of at least et_epipolar_forward_workspace_bytes(desc) bytes, 256-byte
  *               aligned, ZERO-INITIALISED ONCE by the caller when it is allocated: the per-pair pixel

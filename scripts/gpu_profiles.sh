@@ -15,13 +15,13 @@ stats() {  # stats NAME -- bench args...   : rocprofv3 --kernel-trace --stats of
   rm -rf "$OUT/prof_${TAG}_$name"
 }
 echo "== bench (configs[1])"; timeout 900 python bench.py --steps 30 --warmup 5 > "$OUT/${TAG}_bench.json" 2> "$OUT/${TAG}_bench.err"; tail -c 600 "$OUT/${TAG}_bench.json"; echo
-echo "== bench classic (exact fp32 one-block-per-tile kernel)"; timeout 600 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-end-to-end --variant 65536 > "$OUT/${TAG}_bench_variant65536_classic_fp32.json" 2>> "$OUT/${TAG}_bench.err"
+echo "== bench classic (one-block-per-tile kernel, split-fp16 GEMMs)"; timeout 600 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-end-to-end --variant 65536 > "$OUT/${TAG}_bench_variant65536_classic.json" 2>> "$OUT/${TAG}_bench.err"
 echo "== bench per-pixel"; timeout 600 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-end-to-end --variant 16384 > "$OUT/${TAG}_bench_variant16384_perpixel.json" 2>> "$OUT/${TAG}_bench.err"
 echo "== bench config4 head (96x96, K=64, 128 pairs)"; timeout 600 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-end-to-end --hw 96 > "$OUT/${TAG}_bench_config4.json" 2>> "$OUT/${TAG}_bench.err"
 echo "== bench config5 share (128x128, K=128, 8 views x 8 frames = 64 pairs)"; timeout 600 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-end-to-end --samples 128 --hw 128 --frames 8 --views 8 > "$OUT/${TAG}_bench_config5.json" 2>> "$OUT/${TAG}_bench.err"
 python - <<PY
 import json
-for n in ("bench", "bench_variant65536_classic_fp32", "bench_variant16384_perpixel", "bench_config4", "bench_config5"):
+for n in ("bench", "bench_variant65536_classic", "bench_variant16384_perpixel", "bench_config4", "bench_config5"):
     try:
         r = json.load(open("$OUT/${TAG}_%s.json" % n))
         print("%-36s step %.3f ms  fwd %.3f ms  bwd %.3f ms  %.0f pair-views/s" % (n, r["ms_per_step"], r["extra"]["fused_kernel_fwd_ms"], r["extra"]["fused_kernel_bwd_ms"], r["value"]), r["extra"].get("end_to_end", ""))
