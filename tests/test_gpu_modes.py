@@ -303,3 +303,28 @@ def test_general_kernel_gradients_vs_torch_restatement(case):
     names = ["feat1", "feat2", "theta.w", "theta.b", "phi.w", "phi.b", "g.w", "g.b"]
     for nm, gh, gt in zip(names, *grads):
         assert (gh - gt).abs().max().item() <= 2e-4 * max(gt.abs().max().item(), 1e-6), nm
+
+
+def test_general_kernel_rejects_bad_arguments():
+    """Error behaviour of the general entry points (status + message, never a silent wrong result)."""
+    from epipolar_transformers_amd import _lib, camera, ops, synthetic as syn
+
+    H, K, N = 8, 9, 2
+    dev = torch.device("cuda:0")
+    P1, P2 = syn.make_pairs(1, 4, 4 * H, seed=1, jitter=(0.05, 2.0))
+    cam = camera.pair_algebra(P1[:N], P2[:N]).to(dev)
+    spec = ops.LayerSpec(H=H, W=H, K=K)
+    q = torch.randn(N, H, H, 8, device=dev)
+    with pytest.raises(_lib.EpipolarAmdError, match="even K"):
+        ops.forward_general_nhwc(spec, q, q.clone(), q.clone(), cam, pooling=True)                 # POOLING needs an even K
+    big = torch.randn(N, H, H, 516, device=dev)
+    with pytest.raises(_lib.EpipolarAmdError, match="c_sim"):
+        ops.forward_general_nhwc(spec, big, big.clone(), q.clone(), cam)                          # c_sim > 512
+    with pytest.raises(ValueError, match="prior"):
+        ops.forward_general_nhwc(spec, q, q.clone(), q.clone(), cam, prior=torch.zeros(N, K + 1, H, H, device=dev))
+    with pytest.raises(_lib.EpipolarAmdError, match="no CPU fallback"):
+        ops.forward_general_nhwc(spec, q.cpu(), q.cpu(), q.cpu(), cam)
+    with pytest.raises(_lib.EpipolarAmdError, match="PRIOR_MUL"):
+        ops.forward_general_nhwc(spec, q, q.clone(), q.clone(), cam, prior_mul=True)              # multiplies a prior that is not there
+    out, attn, corr = ops.forward_general_nhwc(spec, q, q.clone(), q.clone(), cam)
+    assert torch.isfinite(out).all() and (attn.sum(1) - 1).abs().max().item() < 1e-5
