@@ -6,7 +6,7 @@
 // lanes whose results differ bitwise (they are the same IEEE operations in the same order: any difference is a fault).
 //   hipcc --offload-arch=gfx950 -O3 -ffp-contract=off pk_f32_corun.hip -o /tmp/pk_f32_corun && /tmp/pk_f32_corun
 // Result (MI355X, round 3): 0 differing lanes in every run -- the fault is NOT reproduced by this reduction; it needs more of the
-// real kernel's context (register pressure / spills, the LDS traffic of the row-set lookups, the exact instruction order). && /tmp/pk_f32_corun
+// real kernel's context (register pressure / spills, the LDS traffic of the row-set lookups, the exact instruction order).
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
