@@ -203,3 +203,20 @@ def test_tile_path_eligibility_is_decided_on_the_host(lib):
     f, b = sizes(32, 32, 128, 256)
     assert f > 0 and b == f                                 # K > 64: both tile kernels (K <= 256)
     assert sizes(16, 16, 16, 256, variant=32768)[0] > 0 and sizes(64, 64, 64, 256, variant=32768) == (0, 0)
+
+
+def test_library_is_built_without_slp_vectorisation():
+    """The packed-fp32 instructions SLP vectorisation generates made the one-block-per-tile forward return wrong attention
+    intermittently (scripts/dev/README.md): the flag must not get lost."""
+    from epipolar_transformers_amd import build
+
+    assert "-fno-slp-vectorize" in build.flags()
+    assert "-ffp-contract=off" in build.flags()          # (one rounding per reference op: the parity tests rely on it)
+
+
+def test_outputs_are_poisoned_under_test():
+    from epipolar_transformers_amd import ops
+
+    assert ops.POISON_OUTPUTS, "tests/conftest.py must switch NaN-poisoning of the output buffers on"
+    t = ops._empty((4, 3), device="cpu")
+    assert bool(torch.isnan(t).all())
