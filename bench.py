@@ -59,13 +59,18 @@ def parse():
                     help="replay the step's device work as one hipGraph instead of launching kernel by kernel from Python "
                          "(collective-free partition only; the per-step host algebra runs either way).  Measured: 1.470 vs "
                          "1.481 ms/step -- the step is not launch-bound, so this is not the default")
+    ap.add_argument("--serial-host", action="store_true",
+                    help="compute the per-pair host algebra of a step at the START of that step (rounds 1-3) instead of "
+                         "overlapping it with the device work of the step before")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="skip the extra.config4 / extra.config5 legs (the fused kernels at the head shapes of BASELINE configs[3] / [4])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-end-to-end", action="store_true",
                     help="skip the end-to-end leg (epipolarposeR-50: trunk once per view + layer + head + peaks; views/s of the "
                          "BASELINE metric, carried in extra.end_to_end beside the layer's headline value)")
     ap.add_argument("--cpu-pairs", type=int, default=128, help="pairs in the bounded CPU-baseline sample")
     ap.add_argument("--cpu-reps", type=int, default=1)
-    ap.add_argument("--cpu-ref-pairs", type=int, default=4, help="pairs timed through the reference's op sequence, per thread count")
+    ap.add_argument("--cpu-ref-pairs", type=int, default=16, help="pairs timed through the reference's op sequence at the best thread count (2 per count in the sweep)")
     ap.add_argument("--cpu-threads", type=str, default="8,16,32,64,all", help="thread counts swept for the CPU baselines (best reported)")
     return ap.parse_args()
 
@@ -179,11 +184,24 @@ def main():
             xs.append(fused_layer(ref_c.contiguous(), src_chunk.contiguous(), cam_c.contiguous())[0])
         return xs
 
+    # The per-pair algebra of a step depends on the projection matrices only, and those are known when the batch arrives
+    # from the data loader -- long before its feature maps leave the trunk.  So the algebra of step i + 1
+    # (host, ~0.1-0.4 ms) is computed while the device runs step i: every step still computes exactly one algebra (no
+    # caching), it just does not sit between two launches any more.  --serial-host restores the old order.
+    next_cam = []
+
+    def host_algebra():
+        return camera.pair_algebra(P_ref_pin, P_src_pin).pin_memory().to(dev, non_blocking=True)
+
     def layer_step():
         if exchange is not None:
             return layer_step_view_sharded()
-        cam = camera.pair_algebra(P_ref_pin, P_src_pin).pin_memory().to(dev, non_blocking=True)
-        return fused_layer(feat_ref, feat_src, cam)
+        if args.serial_host:
+            return fused_layer(feat_ref, feat_src, host_algebra())
+        cam = next_cam.pop() if next_cam else host_algebra()
+        res = fused_layer(feat_ref, feat_src, cam)
+        next_cam.append(host_algebra())                      # the following step's, behind this step's launches
+        return res
 
     def barrier():
         torch.cuda.synchronize()
@@ -354,7 +372,9 @@ def main():
                    "partition": args.partition, "layout": "NHWC (channels_last)", "pairs_per_gpu": n_pairs,
                    "variant": args.variant,
                    "launch": "one hipGraph per step (host algebra every step, outside the graph)" if graphed
-                             else "kernel by kernel from Python"},
+                             else "kernel by kernel from Python",
+                   "host_algebra": "per step, at the start of the step" if (args.serial_host or graphed or exchange is not None)
+                                   else "per step, computed for step i+1 while the device runs step i"},
         "roofline": roofline,
         "extra": {"fused_kernel_fwd_ms": kernel_ms, "fused_kernel_bwd_ms": bwd_ms, "fused_kernel_bwd_recompute_ms": bwd_recompute_ms,
                   "kernel_only_pair_views_per_s": n_pairs / (kernel_ms * 1e-3)},
@@ -362,6 +382,13 @@ def main():
     if rg is not None:
         result["extra"]["residual_gemm"] = rg
 
+    ops.check_tile_errors()                  # the sticky device-side error word of the tile forward (synchronises)
+    if rank == 0 and not args.no_other_configs and (V, frames, C, H, K) == (4, 32, 256, 64, 64):
+        del gout, attn_fwd
+        result["extra"]["config4"] = other_config(dev, hw=96, samples=64, views=4, frames=8,
+                                                  name="configs[3] head: 96x96, K=64 (ResNet-152 384x384), 32 pairs")
+        result["extra"]["config5"] = other_config(dev, hw=128, samples=128, views=8, frames=2,
+                                                  name="configs[4] shape: 128x128, K=128 (8 views, 512x512), 16 pairs")
     if rank == 0:
         result["extra"]["mpjpe_delta_mm_vs_reference"] = mpjpe_delta(dev)
     if rank == 0 and not args.no_end_to_end:
@@ -373,6 +400,47 @@ def main():
         print(json.dumps(result))
     if world > 1:
         dist.destroy_process_group()
+
+
+def other_config(dev, hw, samples, views, frames, name, C=256):
+    """The fused forward / backward kernels at another BASELINE head shape (fewer pairs than the headline: same kernels,
+    same per-pair work), HIP events around the calls: ms, pair-views/s and the fraction of the HBM roofline."""
+    from epipolar_transformers_amd import camera, ops, synthetic as syn
+
+    spec = ops.LayerSpec(H=hw, W=hw, K=samples)
+    P1, P2 = syn.make_pairs(frames, views, hw * 4, seed=1000, jitter=(0.05, 8.0))
+    n = P1.shape[0]
+    g = torch.Generator(device=dev).manual_seed(7)
+    ref = torch.randn(n, hw, hw, C, device=dev, generator=g).relu_()
+    src = torch.randn(n, hw, hw, C, device=dev, generator=g).relu_()
+    gout = torch.randn(n, hw, hw, C, device=dev, generator=g)
+    cam = camera.pair_algebra(P1, P2).to(dev)
+
+    def timed(fn, reps=5):
+        for _ in range(2):
+            fn()
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+        for a, b in ev:
+            a.record()
+            fn()
+            b.record()
+        torch.cuda.synchronize()
+        return sum(a.elapsed_time(b) for a, b in ev) / reps
+
+    f_ms = timed(lambda: ops.forward_nhwc(spec, ref, src, cam))
+    attn = ops.forward_nhwc(spec, ref, src, cam)[1]
+    b_ms = timed(lambda: ops.backward_nhwc(spec, ref, src, cam, gout, attn=attn))
+    ops.check_tile_errors()
+    fb = algorithmic_bytes_per_pair(C, hw, hw, samples) * n
+    bb = (5 * C * hw * hw * 4 + samples * hw * hw * 4) * n      # reads feat_ref, feat_src, grad_out, attn; writes both gradients
+    kpl = (samples + 63) // 64
+    rows = 256 if hw <= 64 else (512 if 4 * min(samples, hw) > 384 else 384)
+    return {"workload": name, "pairs": n, "forward_ms": f_ms, "forward_frac_of_hbm_peak": fb / (f_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "forward_pair_views_per_s": n / (f_ms * 1e-3),
+            "forward_kernel": "epipolar_fwd_tile_kernel<%d, %d> (+ tile_order_kernel)" % (kpl, rows) if hw > 64 or samples > 64
+                              else "epipolar_fwd_tile_ws_kernel (+ tile_order_kernel)",
+            "backward_ms": b_ms, "backward_frac_of_hbm_peak": bb / (b_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "algorithmic_bytes_forward": fb, "algorithmic_bytes_backward": bb}
 
 
 def end_to_end(args, dev, P_ref, P_src, frames, V):
@@ -474,20 +542,24 @@ def cpu_baseline(args, spec, feat_ref, feat_src, P_ref, P_src, gpu_same_scope):
     f2 = feat_src[:n_t].permute(0, 3, 1, 2).contiguous().cpu().numpy()
     locs = orc.sample_locs(ospec, P_ref[:n_t], P_src[:n_t])
     sweep_t = {}
+    n_s = min(2, n_t)                                                           # per thread count of the sweep
     for th in counts:
         trp.forward_timed(f1[:1], f2[:1], locs[:, :1], th)                      # warm-up (first call ~2.5x slower)
-        dt_t, _ = trp.forward_timed(f1, f2, locs, th)
-        sweep_t[th] = n_t / dt_t
+        dt_t, _ = trp.forward_timed(f1[:n_s], f2[:n_s], locs[:, :n_s], th)
+        sweep_t[th] = n_s / dt_t
     best_t = max(sweep_t, key=sweep_t.get)
+    dt_t, _ = trp.forward_timed(f1, f2, locs, best_t)                           # the reported figure: the whole sample
+    sweep_t[best_t] = n_t / dt_t
     # kind: the contract knows "reference" (the reference's own binary: there is none to ship -- upstream is Python and
     # does not exist on the GPU box) and "port"; this is a port that keeps the reference's op sequence
     ref = {"value": sweep_t[best_t], "unit": "pair-views/s", "cores": best_t, "kind": "port",
            "implementation": "reference-op-sequence (oracle/torch_ref_path.py, PyTorch CPU)",
            "threads_swept": {str(k): v for k, v in sweep_t.items()}, "host_threads": cores,
            "gpu_same_scope_value": gpu_same_scope,
-           "sample": "%d of the %d pairs of one GPU's batch per thread count, fused sample+attention only (no z/BN), the "
-                     "reference's per-pair op sequence (oracle/torch_ref_path.py) in PyTorch CPU; best of %s threads: %d"
-                     % (n_t, feat_ref.shape[0], "/".join(str(c) for c in counts), best_t)}
+           "sample": "%d of the %d pairs of one GPU's batch at the best thread count (%d; found with %d pairs each at %s "
+                     "threads), fused sample+attention only (no z/BN), the reference's per-pair op sequence "
+                     "(oracle/torch_ref_path.py) in PyTorch CPU"
+                     % (n_t, feat_ref.shape[0], best_t, n_s, "/".join(str(c) for c in counts))}
     # --- the C port
     n = min(args.cpu_pairs, feat_ref.shape[0])
     f1 = feat_ref[:n].permute(0, 3, 1, 2).contiguous().cpu().numpy()

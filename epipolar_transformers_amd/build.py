@@ -59,9 +59,22 @@ _SAFE_FLAGS = ["-fno-slp-vectorize"]
 _UNIT_FLAGS = {}     # per-unit extras (none at present)
 
 
+def _extra_env_flags():
+    """ET_EXTRA_HIPCC_FLAGS, minus anything that would undo _SAFE_FLAGS: a flag that re-enables SLP vectorisation (or
+    contraction: the geometry must round op by op) is refused loudly rather than producing a library that is wrong
+    some of the time."""
+    extra = os.environ.get("ET_EXTRA_HIPCC_FLAGS", "").split()
+    banned = [f for f in extra if f in ("-fslp-vectorize", "-fvectorize", "-ffast-math", "-Ofast") or
+              f.startswith(("-ffp-contract=fast", "-ffp-contract=on")) or (f.startswith("-mllvm") and "slp" in f.lower())]
+    if banned or any("slp-vectorizer" in f or "vectorize-slp" in f for f in extra):
+        raise RuntimeError("ET_EXTRA_HIPCC_FLAGS carries %s: the library must be built without SLP vectorisation and with "
+                           "-ffp-contract=off (build.py: _SAFE_FLAGS, scripts/dev/README.md)" % (banned or extra))
+    return extra
+
+
 def flags():
     return ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC"] + _SAFE_FLAGS + \
-           ["-I" + os.path.join(ROOT, "include"), "-I" + CSRC] + _EXTRA + os.environ.get("ET_EXTRA_HIPCC_FLAGS", "").split()
+           ["-I" + os.path.join(ROOT, "include"), "-I" + CSRC] + _EXTRA + _extra_env_flags()
 
 
 def _obj(unit):

@@ -56,8 +56,6 @@ int et_epipolar_backward_tiled_attn(const EtLayerDesc *desc, const float *xs, co
     p.total_blocks = (int)total;
     tp.hw_words = (HW + 31) / 32;
     tp.rows_cap = tile_rows_cap(desc);
-    int *perm = reinterpret_cast<int *>((reinterpret_cast<uintptr_t>(workspace) + 255) & ~(uintptr_t)255);
-    tp.perm = perm;
     tp.attn = attn;
     hipError_t me = hipMemsetAsync(grad_src, 0, (size_t)desc->N * HW * desc->C * sizeof(float), st);
     if (me != hipSuccess) return fail("hipMemsetAsync(grad_src): %s", hipGetErrorString(me));
@@ -69,9 +67,11 @@ int et_epipolar_backward_tiled_attn(const EtLayerDesc *desc, const float *xs, co
     // (with the per-pair scale estimates of the source maps: the merged kernels run their row-type GEMMs as split-fp16
     //  products; the workspace has the forward's layout)
     const TileWorkspace w = carve_tile_workspace(workspace, (size_t)total, (size_t)desc->N);
+    int *perm = w.perm;
+    tp.perm = perm;
     tp.scales = w.scales;
     hipLaunchKernelGGL(tile_order_kernel, dim3(desc->N), dim3(1024), lds_sort, st, *desc, xs, ys, cam, n2,
-                       tp.tiles_per_pair * kTilePix, perm, (int *)nullptr, feat_ref, feat_src, w.scales, (float4 *)nullptr);
+                       tp.tiles_per_pair * kTilePix, perm, (int *)nullptr, feat_ref, feat_src, w.scales, (float4 *)nullptr, (float4 *)nullptr);
     if (int e = check_launch("et_epipolar_backward_tiled(order)")) return e;
     const int kpl = (desc->K + 63) / 64;
     // 64 x 64 maps, K <= 64: the merged form (two 192-column arrays, one round of atomics per tile) unless the caller

@@ -4,9 +4,9 @@
 
 namespace {
 #include "kernels_forward_tile.inc"     // tile_order_kernel, epipolar_fwd_tile_kernel / _list_kernel
-#include "kernels_forward_tile_ws.inc"  // epipolar_fwd_tile_ws_kernel (warp-specialised, persistent; first generation)
+#include "kernels_forward_tile_ws.inc"  // epipolar_fwd_tile_ws_kernel (warp-specialised, persistent): the default
 #include "kernels_source_planes.inc"    // source_planes_kernel (the source maps as split-fp16 planes, once per call)
-#include "kernels_forward_tile_ws2.inc" // epipolar_fwd_tile_ws2_kernel (second generation: the default)
+#include "kernels_forward_tile_ws2.inc" // epipolar_fwd_tile_ws2_kernel (pre-split source planes; ET_VARIANT_WS_V2 only)
 }  // namespace
 #include "et_tile_host.h"
 
@@ -33,15 +33,14 @@ size_t et_epipolar_forward_workspace_bytes(const EtLayerDesc *desc)
 size_t et_epipolar_forward_workspace_error_offset(const EtLayerDesc *desc)
 {
     if (validate(desc) || !tile_eligible(desc)) return 0;
-    const size_t tiles = (size_t)desc->N * (((size_t)desc->H * desc->W + kTilePix - 1) / kTilePix);
-    return (tiles * kTilePix + 1) * sizeof(int);
+    return sizeof(int);   // word 1 of the header: the same place for every shape (a workspace is reused across shapes)
 }
 
 size_t et_epipolar_forward_workspace_stats_offset(const EtLayerDesc *desc)
 {
     if (validate(desc) || !tile_eligible(desc)) return 0;
     const size_t tiles = (size_t)desc->N * (((size_t)desc->H * desc->W + kTilePix - 1) / kTilePix);
-    return (tiles * kTilePix + 64 + tiles) * sizeof(int);
+    return (kTileWorkspaceHeaderWords + tiles * kTilePix + tiles) * sizeof(int);
 }
 
 int et_epipolar_forward_tiled(const EtLayerDesc *desc, const float *xs, const float *ys, const float *steps,
@@ -91,9 +90,11 @@ int et_epipolar_forward_tiled(const EtLayerDesc *desc, const float *xs, const fl
     // (per-pair scale estimates of the source maps: for the split-fp16 GEMMs of the first-generation persistent kernel and
     //  of the one-block-per-tile kernel; ET_VARIANT_TILE_EXACT keeps the latter in exact fp32)
     float *scales = w.scales;
-    tp.scales = (desc->variant & ET_VARIANT_TILE_EXACT) ? nullptr : w.scales;
+    // soft-max off: exact fp32 throughout, as the header promises (the first GEMM feeds the `== 0 -> -1e10` mask and the
+    // "attention" sim / K is unbounded: no fp16 form of the B rows)
+    tp.scales = ((desc->variant & ET_VARIANT_TILE_EXACT) || !desc->softmax_enabled) ? nullptr : w.scales;
     hipLaunchKernelGGL(tile_order_kernel, dim3(desc->N), dim3(1024), lds_sort, st, *desc, xs, ys, cam, n2,
-                       tp.tiles_per_pair * kTilePix, w.perm, w.ovf_count, feat_ref, feat_src, scales, w.segs);
+                       tp.tiles_per_pair * kTilePix, w.perm, w.ovf_count, feat_ref, feat_src, scales, w.segs, w.band);
     if (int e = check_launch("et_epipolar_forward_tiled(order)")) return e;
     const int kpl = (desc->K + 63) / 64;
     const int rows = tile_rows(desc);
@@ -117,7 +118,7 @@ int et_epipolar_forward_tiled(const EtLayerDesc *desc, const float *xs, const fl
         wp.ovf_count = w.ovf_count;
         wp.ovf_list = w.ovf_list;
         wp.stats = w.stats;
-        wp.err = w.ovf_count + 1;
+        wp.err = w.err;
         wp.segs = w.segs;
         wp.planes = w.planes;
         wp.rowinv = w.rowinv;
@@ -146,7 +147,6 @@ int et_epipolar_forward_tiled(const EtLayerDesc *desc, const float *xs, const fl
         wp.f = p;
         wp.perm = w.perm;
         wp.tiles_per_pair = tp.tiles_per_pair;
-        wp.hw_words = tp.hw_words;
         wp.total_tiles = (int)total;
         wp.rows_cap = tp.rows_cap;
         wp.ovf_count = w.ovf_count;
@@ -154,8 +154,8 @@ int et_epipolar_forward_tiled(const EtLayerDesc *desc, const float *xs, const fl
         wp.stats = w.stats;
         wp.scales = w.scales;
         wp.segs = w.segs;
+        wp.band = w.band;
         wp.setprio = (desc->variant & ET_VARIANT_WS_SETPRIO) ? 1 : 0;
-        wp.div_w_magic = (unsigned)((0x100000000ULL + (unsigned)desc->W - 1) / (unsigned)desc->W);
 #ifdef ET_WS_PROFILE
         wp.prof = g_ws_prof;
         if (const char *e = getenv("ET_WS_EXPERIMENT")) wp.setprio |= atoi(e);
@@ -164,7 +164,7 @@ int et_epipolar_forward_tiled(const EtLayerDesc *desc, const float *xs, const fl
 #endif
         const int cus = device_cus(dev);
         const unsigned grid = (unsigned)(total < cus ? total : cus);
-        const size_t lds_ws = tile_ws_lds_bytes(kTileRowsSmall, tp.hw_words, desc->H, desc->W);
+        const size_t lds_ws = tile_ws_lds_bytes(kTileRowsSmall, desc->H, desc->W);
         ET_SET_LDS((epipolar_fwd_tile_ws_kernel<kTileRowsSmall, 8>), lds_ws);
         hipLaunchKernelGGL((epipolar_fwd_tile_ws_kernel<kTileRowsSmall, 8>), dim3(grid), dim3((kWsMatrixWaves + 8) * kWave),
                            lds_ws, st, wp);

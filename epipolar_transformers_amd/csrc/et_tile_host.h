@@ -46,29 +46,37 @@ bool tile_ws2_eligible(const EtLayerDesc *d)
 }
 
 // Workspace of the tile forward (all int32, base aligned up to 256 bytes):
-//   perm[tiles * 32] | overflow count, [1] sticky error word (64 words) | overflow list[tiles] | stats[tiles] |
-//   scales[4 * N] (float) | segments[tiles * 32] (float4, 16-byte aligned) |
+//   header (64 words): [0] overflow count, [1] sticky error word -- at the front, so that their offsets do not depend on
+//   the shape of the call (a workspace is reused across shapes) |
+//   perm[tiles * 32] | overflow list[tiles] | stats[tiles] | scales[4 * N] (float) |
+//   segments[tiles * 32] (float4, 16-byte aligned) | band[tiles] (float4: the tile's base line, warp-specialised kernel) |
 //   -- warp-specialised kernel, second generation only: --
 //   rowinv[N * HW] (float) | planes[N * HW * 256] (dwords, 256-byte aligned)
 struct TileWorkspace {
-    int *perm, *ovf_count, *ovf_list, *stats;
+    int *perm, *ovf_count, *err, *ovf_list, *stats;
     float *scales;
-    float4 *segs;
+    float4 *segs, *band;
     float *rowinv;
     unsigned *planes;
 };
-size_t tile_workspace_words(size_t tiles, size_t pairs) { return tiles * kTilePix + 64 + 2 * tiles + 4 * pairs + 4 + 4 * tiles * kTilePix; }
+constexpr size_t kTileWorkspaceHeaderWords = 64;
+size_t tile_workspace_words(size_t tiles, size_t pairs)
+{
+    return kTileWorkspaceHeaderWords + tiles * kTilePix + 2 * tiles + 4 * pairs + 4 + 4 * tiles * kTilePix + 4 * tiles;
+}
 size_t tile_workspace_plane_words(size_t pairs, size_t hw) { return pairs * hw + 64 + pairs * hw * 256; }
 TileWorkspace carve_tile_workspace(void *workspace, size_t tiles, size_t pairs, size_t hw = 0)
 {
     TileWorkspace w;
-    w.perm = reinterpret_cast<int *>((reinterpret_cast<uintptr_t>(workspace) + 255) & ~(uintptr_t)255);
-    w.ovf_count = w.perm + tiles * kTilePix;
-    w.ovf_list = w.ovf_count + 64;
+    w.ovf_count = reinterpret_cast<int *>((reinterpret_cast<uintptr_t>(workspace) + 255) & ~(uintptr_t)255);
+    w.err = w.ovf_count + 1;
+    w.perm = w.ovf_count + kTileWorkspaceHeaderWords;
+    w.ovf_list = w.perm + tiles * kTilePix;
     w.stats = w.ovf_list + tiles;
     w.scales = reinterpret_cast<float *>(w.stats + tiles);
     w.segs = reinterpret_cast<float4 *>((reinterpret_cast<uintptr_t>(w.scales + 4 * pairs) + 15) & ~(uintptr_t)15);
-    w.rowinv = reinterpret_cast<float *>(w.segs + tiles * kTilePix);
+    w.band = w.segs + tiles * kTilePix;
+    w.rowinv = reinterpret_cast<float *>(w.band + tiles);
     w.planes = reinterpret_cast<unsigned *>((reinterpret_cast<uintptr_t>(w.rowinv + pairs * hw) + 255) & ~(uintptr_t)255);
     return w;
 }

@@ -8,9 +8,11 @@ the K x C x H x W intermediates are replaced by one fused HIP kernel
 The mode every headline config runs -- ATTENTION avg, SIMILARITY dot, soft-max on or off,
 optional 'z' (+BN, +ZRESIDUAL), either normalize convention -- takes the fused HIP kernels.  The operator's
 other branches (theta/phi/g bottleneck, POOLING, ATTENTION max, cosine similarity,
-PRIOR / PRIORMUL, FIND_CORR rgb -- e.g. configs/epipolar/keypoint_h36m_param.yaml) run on the GPU as a restatement
-of the reference's own op sequence (`_attend_general`): the sample locations still come from the HIP geometry
-kernel (bit-equal to grid2sample_locs), the resampling / pooling / similarity are batched torch ops with autograd.
+PRIOR / PRIORMUL, FIND_CORR rgb -- e.g. configs/epipolar/keypoint_h36m_param.yaml) run through ONE general HIP kernel
+over three tensors (`_attend_general_hip` -> et_epipolar_forward_general; HIP backward for the dot-product branches
+without a prior).  What is left to a torch restatement of the reference's op sequence (`_attend_general_chunk`, chunked
+over pairs): SIMILARITY prior, and the prior / cosine / ATTENTION max branches WHEN A GRADIENT IS REQUESTED -- about 5x
+slower than the kernel; the first such call of a process says so in a warning (`EpipolarSlowPathWarning`).
 The reprojection loss and an externally supplied depth raise NotImplementedError.
 """
 from __future__ import annotations
@@ -25,6 +27,31 @@ import torch.nn.functional as F
 from . import ops
 from .camera import PairAlgebraCache
 from .config import amd_knob, get_cfg
+
+
+_ANY = object()     # `_general_kernel_applies`: "camera ids not part of the question" (routing queries of the tests)
+
+
+class EpipolarSlowPathWarning(UserWarning):
+    """A call took the chunked torch restatement instead of a HIP kernel (see the module docstring)."""
+
+
+_warned_slow = False
+
+
+def _warn_slow_path(cfg):
+    global _warned_slow
+    if _warned_slow:
+        return
+    _warned_slow = True
+    import warnings
+
+    e = cfg.EPIPOLAR
+    warnings.warn("Epipolar: this configuration (ATTENTION %s, SIMILARITY %s, PRIOR %s, POOLING %s, gradients %s) runs the "
+                  "chunked torch restatement of the reference's op sequence, not a HIP kernel -- about 5x slower than the "
+                  "general kernel the same configuration takes under torch.no_grad()" %
+                  (e.ATTENTION, e.SIMILARITY, e.PRIOR, e.POOLING, torch.is_grad_enabled()), EpipolarSlowPathWarning,
+                  stacklevel=3)
 
 
 class zeroinitBN(nn.BatchNorm2d):
@@ -108,8 +135,9 @@ class Epipolar(nn.Module):
         """`_attend_general_chunk` over ranges of pairs, so that the sampled K x C x H x W tensors (what the reference
         materialises per PAIR, epipolar.py:199-213) never exceed ~2 GB at once however large the batch is
         (keypoint_h36m_param.yaml at 32 frames x 4 views would otherwise hold 17 GB per sampled map)."""
-        if self._general_kernel_applies(feat1, feat2, ref1, ref2):
+        if self._general_kernel_applies(feat1, feat2, ref1, ref2, camera, other_camera):
             return self._attend_general_hip(feat1, feat2, P1, P2, camera, other_camera, ref1, ref2)
+        _warn_slow_path(self.cfg)
         N, C, H, W = feat2.shape
         per_pair = 2 * self.sample_size * max(C, feat1.shape[1]) * H * W * 4 * (2 if torch.is_grad_enabled() else 1)
         step = max(1, int(amd_knob(self.cfg, "GENERAL_MODE_BYTES", 2 << 30)) // per_pair)
@@ -121,7 +149,7 @@ class Epipolar(nn.Module):
                                             sl(ref2, a, a + step)) for a in range(0, N, step)]
         return tuple(torch.cat([p[i] for p in parts]) for i in range(3))
 
-    def _general_kernel_applies(self, feat1, feat2, ref1=None, ref2=None) -> bool:
+    def _general_kernel_applies(self, feat1, feat2, ref1=None, ref2=None, camera=_ANY, other_camera=_ANY) -> bool:
         """True when the HIP general kernels compute this call.  Forward (`et_epipolar_forward_general`): every branch of
         a12 / N4 -- theta / phi / g, BOTTLENECK, POOLING, PRIOR / PRIORMUL, SIMILARITY cos, ATTENTION max, FIND_CORR rgb --
         except SIMILARITY prior.  With a gradient requested (`et_epipolar_backward_general`, through ops.GeneralAttend):
@@ -134,6 +162,11 @@ class Epipolar(nn.Module):
         if not bool(amd_knob(self.cfg, "GENERAL_KERNEL", True)) or not feat2.is_cuda:
             return False
         if e.POOLING and self.sample_size % 2:
+            return False
+        if e.PRIOR and (e.POOLING or camera is None or other_camera is None):
+            # the prior tables are (K, H, W) per camera pair: with POOLING the reference's own shapes disagree (K/2
+            # similarities against K prior rows, epipolar.py:200-224), and without camera ids there is no table to pick --
+            # both take the restatement and fail there with the reference's own error instead of one from inside ops
             return False
         if (e.PRIOR or e.ATTENTION == "max" or e.SIMILARITY == "cos") and torch.is_grad_enabled():
             params = [q for k in ("theta", "phi", "g") if k in e.PARAMETERIZED for q in getattr(self, k).parameters()]

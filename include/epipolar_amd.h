@@ -122,27 +122,36 @@ int et_epipolar_forward(const EtLayerDesc *desc, const float *xs, const float *y
  * their epipolar line, 32 neighbouring lines form a tile, and the channel-long work of the tile runs
  * as two GEMMs on the matrix cores against the union of the source rows the tile touches (each source
  * row is fetched per tile, not per pixel).  For K <= 64 on maps up to 64 x 64 with the soft-max on
- * (every headline config) the call is: one pass that rewrites the source maps as split-fp16 planes
- * (one dword ( hi | lo << 16 ) per value, one exact power-of-two scale per pixel row; kept in the
- * workspace), then one persistent block per compute unit whose waves are specialised (matrix waves run
- * the two GEMMs of consecutive tiles back to back as fp16 MFMAs with fp32 accumulation, ~22
- * significant bits per product; vector waves do the geometry / soft-max work of the neighbouring tiles
- * meanwhile).  Other shapes (maps above 64 x 64, K > 64) run one block per tile with the same split-fp16
- * GEMMs; a tile with a value beyond fp16's range, and every call with the soft-max off, is computed in
- * exact fp32 (ET_VARIANT_TILE_EXACT: always).  Same arguments and results as
- * et_epipolar_forward (rounding differs at the 1e-6 level: the sums are re-associated), plus
+ * (every headline config) the call is one persistent block per compute unit whose waves are
+ * specialised: matrix waves run the two GEMMs of consecutive tiles back to back as split-fp16 MFMAs
+ * with fp32 accumulation (~22 significant bits per product; the fp32 operands are scaled by powers of
+ * two, split into fp16 hi + lo at the point of use and every converted value is range-checked), vector
+ * waves do the geometry / row-set / soft-max work of the neighbouring tiles meanwhile.
+ * ET_VARIANT_WS_V2 selects a second form of that kernel that first rewrites the source maps as
+ * split-fp16 planes (one dword ( hi | lo << 16 ) per value, one exact power-of-two scale per pixel row;
+ * kept in the workspace) -- measured slower on MI355X, not the default.  Other shapes (maps above
+ * 64 x 64, K > 64) run one block per tile with the same split-fp16 GEMMs.  A tile with a value beyond
+ * fp16's range is redone in exact fp32, and so is every call with the soft-max off
+ * (EPIPOLAR.SOFTMAX_ENABLED False: the "attention" sim / K is unbounded) and every call with
+ * ET_VARIANT_TILE_EXACT.  Same arguments and results as et_epipolar_forward (rounding differs at the
+ * 1e-6 level: the sums are re-associated), plus
  *   workspace : device scratch of at least et_epipolar_forward_workspace_bytes(desc) bytes, 256-byte
- *               aligned, ZERO-INITIALISED ONCE by the caller when it is allocated: the per-pair pixel
- *               order, the overflow-tile list, the source planes (as large as feat_src) and
+ *               aligned, ZERO-INITIALISED ONCE by the caller when it is allocated.  It starts with a
+ *               64-word header -- word 0 the overflow-tile count, word 1 a STICKY int32 error word
+ *               (et_epipolar_forward_workspace_error_offset(desc) = 4 bytes in, whatever the shape, so
+ *               that a workspace reused across shapes keeps ONE error word: the kernels only ever OR
+ *               bits into it; bit 0: a wave of a persistent kernel gave up waiting at an internal
+ *               barrier -- the results of that call are invalid.  Only the ET_VARIANT_WS_V2 kernel has
+ *               such a barrier; the default kernel's waves never wait on each other outside the
+ *               hardware barrier.  The library never synchronises, so the caller reads the word when
+ *               it synchronises anyway: ops.check_tile_errors in the Python binding) -- followed by
+ *               the per-pair pixel order, the overflow-tile list, per-pair scales, the epipolar
+ *               segments and one base line per tile (with ET_VARIANT_WS_V2 also the source planes,
+ *               as large as feat_src), and
  *                 - one int32 of statistics per tile ( U | groups << 16 : size of the tile's
  *                   source-row set, number of groups it was split into) starting
  *                   et_epipolar_forward_workspace_stats_offset(desc) bytes in, in tile order
- *                   (pair-major), readable by the caller after the call;
- *                 - one STICKY int32 error word et_epipolar_forward_workspace_error_offset(desc) bytes
- *                   in: the kernels only ever OR bits into it (bit 0: a wave of the persistent kernel
- *                   gave up waiting at its internal barrier -- results of that call are invalid).  The
- *                   library never synchronises, so the caller reads it when it synchronises anyway
- *                   (the Python binding: ops.check_tile_errors) -- no error is swallowed silently.
+ *                   (pair-major), readable by the caller after the call.
  * et_epipolar_forward_workspace_bytes returns 0 when the tile path does not apply to `desc`
  * (then et_epipolar_forward_tiled fails and et_epipolar_forward is the path to call). */
 size_t et_epipolar_forward_workspace_bytes(const EtLayerDesc *desc);

@@ -39,11 +39,11 @@ raw.et_dev_ws_profile(None)
 p = prof.cpu().numpy().reshape(256, 4 + nv, 12).astype(np.float64) / 64.0      # cycles per tile (64 tiles per block)
 m, v = p[:, :4], p[:, 4:]
 names_m = ["G2 prefetch", "wait A", "G2", "G1 prefetch", "wait B", "copy load", "G1", "matrix barrier", "copy finish"]
-names_v = ["SM tail (scatter)", "S1", "vbar", "S2", "wait A", "merge+copy+zero", "wait B", "-", "SM front", "SM softmax", "SM corr"]
+names_v = ["SM attn store", "S1", "arrive", "S2 (last wave)", "wait A", "copy finish", "wait B", "SM tail (B rows, phase A)", "SM front", "SM softmax", "SM corr"]
 print("cycles per tile (mean over blocks; per wave index)")
 if os.environ.get("WS_PROFILE_LIGHT"):
     ma = m[:, :, 5] + m[:, :, 6] + m[:, :, 0]; mb = m[:, :, 3]
-    va = v[:, :, 1] + v[:, :, 3]; vb = v[:, :, 0] + v[:, :, 5]
+    va = v[:, :, 1] + v[:, :, 3] + v[:, :, 7]; vb = v[:, :, 0] + v[:, :, 5]
     r = lambda a: np.round(a.mean(0)).astype(int).tolist()
     print("matrix waves: phase A work %s  wait A %s  phase B work %s  wait B %s" % (r(ma), r(m[:, :, 1]), r(mb), r(m[:, :, 4])))
     print("vector waves: phase A work %s  wait A %s  phase B work %s  wait B %s" % (r(va), r(v[:, :, 4]), r(vb), r(v[:, :, 6])))

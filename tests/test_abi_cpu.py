@@ -179,7 +179,8 @@ def test_tile_path_eligibility_is_decided_on_the_host(lib):
         # pixel order (32 per tile) | overflow counter + sticky error word (64 words) | overflow list | statistics | scales |
         # segments [| 1 / scale of every source row | alignment | source planes: the warp-specialised kernel (K <= 64, maps
         # up to 64 x 64, soft-max on) keeps the source maps as split-fp16 dwords, as large as feat_src]
-        words = tiles * 32 + 64 + 2 * tiles + 4 * pairs + 4 + 4 * tiles * 32
+        # (header of 64 words first: [0] overflow count, [1] sticky error word; one float4 base line per tile last)
+        words = 64 + tiles * 32 + 2 * tiles + 4 * pairs + 4 + 4 * tiles * 32 + 4 * tiles
         if plane_hw:
             words += pairs * plane_hw + 64 + pairs * plane_hw * 256
         return words * 4 + 256
@@ -194,8 +195,11 @@ def test_tile_path_eligibility_is_decided_on_the_host(lib):
     assert sizes(96, 96, 64, 256)[0] == ws_bytes(3 * 288)           # config 4: 384-row tiles
     assert sizes(10, 10, 16, 256)[0] == ws_bytes(3 * 4)             # 100 pixels -> 4 padded tiles
     d = ops.LayerSpec(H=64, W=64, K=64).desc(3, 256)
-    assert int(lib.et_epipolar_forward_workspace_stats_offset(ctypes.byref(d))) == (3 * 128 * 32 + 64 + 3 * 128) * 4
-    assert int(lib.et_epipolar_forward_workspace_error_offset(ctypes.byref(d))) == (3 * 128 * 32 + 1) * 4
+    assert int(lib.et_epipolar_forward_workspace_stats_offset(ctypes.byref(d))) == (64 + 3 * 128 * 32 + 3 * 128) * 4
+    # the sticky error word sits in the header: the same offset whatever the shape (a cached workspace is reused across shapes)
+    for shape in ((64, 64, 64), (96, 96, 64), (16, 16, 16)):
+        dd = ops.LayerSpec(H=shape[0], W=shape[1], K=shape[2]).desc(5, 256)
+        assert int(lib.et_epipolar_forward_workspace_error_offset(ctypes.byref(dd))) == 4
     assert sizes(64, 64, 64, 128) == (0, 0)                 # other channel counts: per-pixel kernels
     f5, b5 = sizes(128, 128, 128, 256)
     assert f5 == b5 == ws_bytes(3 * 512)                    # config 5: 512-row tiles, K = 128 (two samples per lane)
@@ -212,6 +216,21 @@ def test_library_is_built_without_slp_vectorisation():
 
     assert "-fno-slp-vectorize" in build.flags()
     assert "-ffp-contract=off" in build.flags()          # (one rounding per reference op: the parity tests rely on it)
+    # ... and cannot be undone from the environment
+    import os
+    keep = os.environ.get("ET_EXTRA_HIPCC_FLAGS")
+    try:
+        for bad in ("-fslp-vectorize", "-mllvm -vectorize-slp=true", "-ffast-math", "-ffp-contract=fast"):
+            os.environ["ET_EXTRA_HIPCC_FLAGS"] = bad
+            with pytest.raises(RuntimeError):
+                build.flags()
+        os.environ["ET_EXTRA_HIPCC_FLAGS"] = "-DET_WS_PROFILE=2"
+        assert "-DET_WS_PROFILE=2" in build.flags()
+    finally:
+        if keep is None:
+            os.environ.pop("ET_EXTRA_HIPCC_FLAGS", None)
+        else:
+            os.environ["ET_EXTRA_HIPCC_FLAGS"] = keep
 
 
 def test_outputs_are_poisoned_under_test():

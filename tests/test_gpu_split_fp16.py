@@ -35,24 +35,25 @@ def env():
     return _lib, camera, ops
 
 
-def _pairs(frames=1, seed=3):
+def _pairs(frames=1, seed=3, h=H):
     from epipolar_transformers_amd import synthetic as syn
 
-    return syn.make_pairs(frames, 4, 4 * H, seed=seed, jitter=(0.05, 8.0))
+    return syn.make_pairs(frames, 4, 4 * h, seed=seed, jitter=(0.05, 8.0))
 
 
-def _features(n, seed, kind="relu"):
+def _features(n, seed, kind="relu", h=H):
     g = torch.Generator().manual_seed(seed)
     if kind == "relu":
-        return torch.randn(n, C, H, W, generator=g).relu(), torch.randn(n, C, H, W, generator=g).relu()
+        return torch.randn(n, C, h, h, generator=g).relu(), torch.randn(n, C, h, h, generator=g).relu()
     if kind == "lognormal":
-        return torch.exp(2.0 * torch.randn(n, C, H, W, generator=g)), torch.exp(2.0 * torch.randn(n, C, H, W, generator=g))
+        return torch.exp(2.0 * torch.randn(n, C, h, h, generator=g)), torch.exp(2.0 * torch.randn(n, C, h, h, generator=g))
     raise ValueError(kind)
 
 
-def _compare(env, oracle_mod, P1, P2, f1, f2, variants=(0,), softmax=True, attn_tol=1e-5, out_rel=1e-4):
+def _compare(env, oracle_mod, P1, P2, f1, f2, variants=(0,), softmax=True, attn_tol=1e-5, out_rel=1e-4, k=K):
     """HIP forward (through the C ABI) vs the C oracle on the same inputs and the same per-pair algebra."""
     _lib, camera, ops = env
+    H, W, K = f1.shape[2], f1.shape[3], k
     cam = camera.pair_algebra(P1, P2)
     want = oracle_mod.forward(oracle_mod.LayerSpec(H, W, K, softmax_enabled=softmax), f1, f2, None, None, cam=cam.numpy())
     assert np.isfinite(want["out"]).all() and np.isfinite(want["attn"]).all()
@@ -74,6 +75,7 @@ def _compare(env, oracle_mod, P1, P2, f1, f2, variants=(0,), softmax=True, attn_
         assert ea <= attn_tol, "variant %d: attention differs from the oracle by %g" % (v, ea)
         assert eo <= 1.0, "variant %d: out differs by %g x its tolerance (output magnitude %g)" % (v, eo, gmax)
         assert_corr_pos(want["sample_locs"], corr, want["corr_pos"], attn, True, max_frac=2e-2)
+        ops.check_tile_errors()
     return want, worst
 
 
@@ -203,3 +205,110 @@ def test_one_block_per_tile_split_kernel_is_stable_over_repeated_runs(shape):
         o, a, c = ops.forward_nhwc(ops.LayerSpec(H=H, W=H, K=K, variant=variant), ref, src, cam)
         ok = ((a - a0).abs().amax(1) <= 1e-5) & ((o - o0).abs().amax(-1) <= tol_o) & ~torch.isnan(c).any(-1)
         assert bool(ok.all()), "run %d: %d pixels differ" % (rep, int((~ok).sum()))
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The same regimes where BASELINE configs[3] / [4] live: 96 x 96 maps (K = 64: epipolar_fwd_tile_kernel<1, 384>) and 128 x 128
+# maps with K = 128 (<2, 512>) -- the one-block-per-tile kernel with its split first GEMM in TWO passes, its guard and its
+# exact-fp32 redo -- and for the tiled backward, whose five split-fp16 GEMMs otherwise only ever see relu(randn).
+# ---------------------------------------------------------------------------------------------------------------------
+BIG_SHAPES = [pytest.param(96, 64, 4, id="96x96-K64"), pytest.param(128, 128, 2, id="128x128-K128")]
+
+
+def _lognormal_scaled(n, seed, h, target=80.0):
+    f1, f2 = _features(n, seed=seed, kind="lognormal", h=h)
+    g = torch.Generator().manual_seed(2)
+    a = f1.permute(0, 2, 3, 1).reshape(-1, C)[torch.randint(0, n * h * h, (100000,), generator=g)]
+    b = f2.permute(0, 2, 3, 1).reshape(-1, C)[torch.randint(0, n * h * h, (100000,), generator=g)]
+    s = float((target / torch.quantile((a * b).sum(1), 0.9999).item()) ** 0.5)
+    return f1 * s, f2 * s
+
+
+@pytest.mark.parametrize("h,k,n", BIG_SHAPES)
+@pytest.mark.parametrize("regime", ["outliers", "lognormal", "tiny_x_huge", "huge_x_tiny", "tiny_row"])
+def test_large_maps_split_fp16_regimes(env, oracle_mod, h, k, n, regime):
+    P1, P2 = _pairs(h=h)
+    P1, P2 = P1[:n], P2[:n]
+    attn_tol = 1e-5
+    if regime == "outliers":
+        f1, f2 = _features(n, seed=31, h=h)
+        for i, (y, x, ch, mag) in enumerate([(20, 0, 17, 3.0e4), (0, 0, 100, 3.0e3), (h - 1, h - 1, 5, -3.0e4), (h // 2, 1, 9, 6.0e4)]):
+            q = i % n
+            if i % 2 == 0:
+                f2[q, ch, y, x] = mag
+                f1[q, ch] = 0
+            else:
+                f1[q, ch, y, x] = mag
+                f2[q, ch] = 0
+    elif regime == "lognormal":
+        f1, f2 = _lognormal_scaled(n, 33, h)
+        attn_tol = 3e-5
+    elif regime == "tiny_x_huge":
+        f1, f2 = _features(n, seed=35, h=h)
+        f1, f2 = f1 * 1e-6, f2 * 1e6
+    elif regime == "huge_x_tiny":
+        f1, f2 = _features(n, seed=37, h=h)
+        f1, f2 = f1 * 3e4, f2 * 3.3e-5
+    else:
+        f1, f2 = _features(n, seed=39, h=h)
+        f2[:, :, :, : h // 2] = 0
+        tiny = torch.rand(C, generator=torch.Generator().manual_seed(1)) * float(2.0 ** -40)
+        for q in range(n):
+            for (y, x) in [(5, 7), (h // 2 - 1, h // 2), (h - 4, 3), (h // 2 + 1, h // 2 + 1)]:
+                f1[q, :, y, x] = tiny
+        f1[0, :, 40, 40] = float(2.0 ** -100)
+    _compare(env, oracle_mod, P1, P2, f1, f2, variants=(0,), attn_tol=attn_tol, k=k)
+
+
+BWD_SHAPES = [pytest.param(64, 64, 2, id="64x64-K64"), pytest.param(96, 64, 1, id="96x96-K64"),
+              pytest.param(128, 128, 1, id="128x128-K128")]
+
+
+@pytest.mark.parametrize("h,k,n", BWD_SHAPES)
+@pytest.mark.parametrize("regime", ["lognormal", "outliers", "tiny_x_huge", "huge_grad"])
+def test_tiled_backward_split_fp16_regimes(env, oracle_mod, h, k, n, regime):
+    """backward_nhwc(form="tile") -- reusing the forward's attention, as autograd does, and recomputing it -- against the
+    oracle's backward (fp32 restatement of the reference's autograd) at 1e-4 of each gradient's magnitude."""
+    _lib, camera, ops = env
+    P1, P2 = _pairs(h=h)
+    P1, P2 = P1[:n], P2[:n]
+    g = torch.Generator().manual_seed(41)
+    go = torch.randn(n, C, h, h, generator=g)
+    if regime == "lognormal":
+        f1, f2 = _lognormal_scaled(n, 43, h, target=40.0)
+        go = go * torch.exp(1.5 * torch.randn(n, C, h, h, generator=g))
+    elif regime == "outliers":
+        f1, f2 = _features(n, seed=45, h=h)
+        f2[0, 17, 20, 0] = 3.0e4
+        f1[0, 17] = 0
+        f1[n - 1, 100, h - 1, h - 1] = 3.0e3
+        f2[n - 1, 100] = 0
+        go[0, 7, 3, 3] = 1.0e4
+        go[n - 1, 200, h // 2, 5] = -3.0e4
+    elif regime == "tiny_x_huge":
+        f1, f2 = _features(n, seed=47, h=h)
+        f1, f2 = f1 * 1e-6, f2 * 1e6
+        go = go * 1e-6
+    else:
+        f1, f2 = _features(n, seed=49, h=h)
+        go = go * 1e4
+    cam = camera.pair_algebra(P1, P2)
+    so = oracle_mod.LayerSpec(h, h, k)
+    want = oracle_mod.forward(so, f1, f2, None, None, cam=cam.numpy())
+    g1, g2 = oracle_mod.backward(so, f1.numpy(), f2.numpy(), want["sample_locs"], go.numpy())
+    assert np.isfinite(g1).all() and np.isfinite(g2).all()
+    ref, src, gout = ops.to_nhwc(f1.cuda()), ops.to_nhwc(f2.cuda()), ops.to_nhwc(go.cuda())
+    spec = ops.LayerSpec(H=h, W=h, K=k)
+    attn = ops.forward_nhwc(spec, ref, src, cam.cuda())[1]
+    for kw in (dict(attn=attn), dict()):
+        gr, gs = ops.backward_nhwc(spec, ref, src, cam.cuda(), gout, form="tile", **kw)
+        torch.cuda.synchronize()
+        for got, wantg, nm in ((gr, g1, "grad_ref"), (gs, g2, "grad_src")):
+            got = got.permute(0, 3, 1, 2).cpu().numpy()
+            assert np.isfinite(got).all(), nm
+            # per (pair, channel) scale, never below 5 % of the pair's largest gradient (the products of a tile share
+            # power-of-two scales: their rounding is relative to the tile's largest term, like an fp32 GEMM's)
+            scale = np.maximum(np.abs(wantg).max(axis=(2, 3), keepdims=True),
+                               0.05 * np.abs(wantg).max(axis=(1, 2, 3), keepdims=True) + 1e-30)
+            err = float((np.abs(got - wantg) / scale).max())
+            assert err <= 1e-4, "%s (%s, attn %s): %g of the channel's magnitude" % (nm, regime, "reused" if kw else "recomputed", err)
