@@ -163,11 +163,14 @@ class Epipolar(nn.Module):
             return False
         if e.POOLING and self.sample_size % 2:
             return False
-        if e.PRIOR and (e.POOLING or camera is None or other_camera is None):
-            # the prior tables are (K, H, W) per camera pair: with POOLING the reference's own shapes disagree (K/2
-            # similarities against K prior rows, epipolar.py:200-224), and without camera ids there is no table to pick --
-            # both take the restatement and fail there with the reference's own error instead of one from inside ops
-            return False
+        if e.PRIOR:
+            # the reference builds its prior tables with K rows (epipolar.py:70-80); with POOLING the similarities have K/2
+            # (epipolar.py:200-224) and its own shapes disagree.  The kernel takes tables of K' = K/2 rows then; anything else,
+            # or a call without camera ids (no table to pick), goes to the restatement and fails there with the reference's
+            # own error instead of one from inside ops
+            rows = self.sample_size // 2 if e.POOLING else self.sample_size
+            if camera is None or other_camera is None or any(t.shape[0] != rows for t in self.prior.values()):
+                return False
         if (e.PRIOR or e.ATTENTION == "max" or e.SIMILARITY == "cos") and torch.is_grad_enabled():
             params = [q for k in ("theta", "phi", "g") if k in e.PARAMETERIZED for q in getattr(self, k).parameters()]
             params += list(self.prior.values()) if e.PRIOR else []

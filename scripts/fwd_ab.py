@@ -1,0 +1,35 @@
+#!/usr/bin/env python
+"""Lean A/B timing of the fused forward at Config 2 (development): one process per library variant.
+    EPIPOLAR_AMD_LIB=.../libepipolar_amd_X.so python scripts/fwd_ab.py [label]"""
+import os, sys
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from epipolar_transformers_amd import _lib, camera, ops, synthetic as syn
+
+label = sys.argv[1] if len(sys.argv) > 1 else os.path.basename(os.environ.get("EPIPOLAR_AMD_LIB", "default"))
+dev = torch.device("cuda:0")
+H, C, K = 64, 256, 64
+P1, P2 = syn.make_pairs(32, 4, H * 4, seed=1000, jitter=(0.05, 8.0))
+g = torch.Generator(device=dev).manual_seed(0)
+ref = torch.randn(128, H, H, C, device=dev, generator=g).relu_()
+src = torch.randn(128, H, H, C, device=dev, generator=g).relu_()
+cam = camera.pair_algebra(P1, P2).to(dev)
+spec = ops.LayerSpec(H=H, W=H, K=K)
+ws = ops.tile_workspace(spec, 128, C, dev)
+for _ in range(5):
+    ops.forward_nhwc(spec, ref, src, cam, workspace=ws)
+ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(40)]
+torch.cuda.synchronize()
+for a, b in ev:
+    a.record()
+    ops.forward_nhwc(spec, ref, src, cam, workspace=ws)
+    b.record()
+torch.cuda.synchronize()
+t = sorted(a.elapsed_time(b) for a, b in ev)
+base = (-ws.data_ptr()) % 256
+ovf = int(ws[base:base + 4].view(torch.int32).item())
+o, a_, c_ = ops.forward_nhwc(spec, ref[:8], src[:8], cam[:8])
+o2, a2, c2 = ops.forward_nhwc(ops.LayerSpec(H=H, W=H, K=K, variant=_lib.ET_VARIANT_NO_TILE), ref[:8], src[:8], cam[:8])
+print("%-28s forward call %.4f ms (min %.4f, p90 %.4f)  overflow tiles %d  | vs per-pixel: out %.2e attn %.2e corr mismatch %.5f"
+      % (label, sum(t) / len(t), t[0], t[int(0.9 * len(t))], ovf, (o - o2).abs().max().item(), (a_ - a2).abs().max().item(),
+         (c_ != c2).any(-1).float().mean().item()), flush=True)

@@ -20,7 +20,15 @@ for step in "$@"; do
       echo "== bench"; timeout 900 python bench.py --steps 30 --warmup 5 > "$OUT/bench_$TAG.json" 2> "$OUT/bench_$TAG.err"; echo "bench exit $?"
       cat "$OUT/bench_$TAG.json"; tail -5 "$OUT/bench_$TAG.err";;
     convprobe)
-      echo "== conv probe"; timeout 900 python scripts/conv_probe.py --image 384 --batch 32 > "$OUT/convprobe_$TAG.txt" 2>&1; echo "convprobe exit $?"; grep -v amdgpu.ids "$OUT/convprobe_$TAG.txt" | tail -50;;
+      echo "== conv probe"; timeout 900 python scripts/conv_probe.py --image 384 --batch ${CONV_BATCH:-32} --settings ${CONV_SETTINGS:-cl0,cl1,nchw0,nchw1} > "$OUT/convprobe_$TAG.txt" 2>&1; echo "convprobe exit $?"; grep -v amdgpu.ids "$OUT/convprobe_$TAG.txt" | tail -50;;
+    benchmodes)
+      echo "== bench: host algebra overlapped / serial / graph"
+      for m in "" "--serial-host" "--graph"; do
+        timeout 600 python bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-end-to-end --no-other-configs $m > "$OUT/benchmode_$TAG.json" 2>> "$OUT/bench_$TAG.err"
+        python -c "import json;r=json.load(open('$OUT/benchmode_$TAG.json'));print('mode [$m]: ms_per_step %.4f  fwd call %.4f  residual gemm %.4f' % (r['ms_per_step'], r['roofline']['kernel_ms'], r['extra']['residual_gemm']['kernel_ms']))"
+      done;;
+    hostprobe)
+      echo "== host algebra"; timeout 300 python scripts/host_probe.py > "$OUT/hostprobe_$TAG.txt" 2>&1; grep -v amdgpu.ids "$OUT/hostprobe_$TAG.txt" | tail -30;;
     rocprof)
       echo "== rocprof"
       (cd /tmp && export TMPDIR=/tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_$TAG" -o trace -- python "$ROOT/bench.py" --steps 10 --warmup 3 --no-cpu-baseline > "$OUT/rocprof_$TAG.log" 2>&1; echo "rocprof exit $?")
