@@ -411,7 +411,10 @@ def main():
     if rank == 0:
         result["extra"]["mpjpe_delta_mm_vs_reference"] = mpjpe_delta(dev)
     if rank == 0 and not args.no_end_to_end:
-        result["extra"]["end_to_end"] = end_to_end(args, dev, P_ref, P_src, frames, V)
+        result["extra"]["end_to_end"] = end_to_end(dev, args.hw, args.samples, args.channels, frames, V)
+        if "config4" in result["extra"]:
+            # BASELINE configs[3] names ResNet-152 at 384 x 384 (keypoint_h36m_resnet152_384_pretrained_8gpu.yaml:7,18,27)
+            result["extra"]["config4"]["end_to_end"] = end_to_end(dev, 96, 64, 256, 8, 4, body="epipolarposeR-152")
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"], result["cpu_baseline_port"] = cpu_baseline(args, spec, feat_ref, src, P_ref, P_src,
                                                                            n_pairs / (kernel_ms * 1e-3))
@@ -462,24 +465,25 @@ def other_config(dev, hw, samples, views, frames, name, C=256):
             "algorithmic_bytes_forward": fb, "algorithmic_bytes_backward": bb}
 
 
-def end_to_end(args, dev, P_ref, P_src, frames, V):
-    """epipolarposeR-50 on `frames` x V synthetic 256x256 images (random init, fp32, eval): the trunk runs ONCE per
+def end_to_end(dev, hw, samples, channels, frames, V, body="epipolarposeR-50"):
+    """`body` on `frames` x V synthetic images of 4 hw x 4 hw (random init, fp32, eval): the trunk runs ONCE per
     view (the reference runs it twice per pair, model.py:241-247 -- SURVEY.md N1), its channels_last deconv
     features feed the fused layer directly, then the 1x1 head and the batched peak finder."""
-    from epipolar_transformers_amd import default_cfg
+    from epipolar_transformers_amd import default_cfg, synthetic as syn
     from epipolar_transformers_amd.model import MultiViewPoseModel, ring_sources
 
     cfg = default_cfg()
-    cfg.merge_from_list(["BACKBONE.BODY", "epipolarposeR-50", "BACKBONE.PRETRAINED", False,
-                         "KEYPOINT.HEATMAP_SIZE", (args.hw, args.hw), "KEYPOINT.NUM_PTS", 17, "KEYPOINT.SIGMA", 8.0,
-                         "KEYPOINT.NFEATS", args.channels, "DATASETS.IMAGE_SIZE", (args.hw * 4, args.hw * 4),
+    cfg.merge_from_list(["BACKBONE.BODY", body, "BACKBONE.PRETRAINED", False,
+                         "KEYPOINT.HEATMAP_SIZE", (hw, hw), "KEYPOINT.NUM_PTS", 17, "KEYPOINT.SIGMA", 8.0,
+                         "KEYPOINT.NFEATS", channels, "DATASETS.IMAGE_SIZE", (hw * 4, hw * 4),
                          "EPIPOLAR.MERGE", "late", "EPIPOLAR.ATTENTION", "avg", "EPIPOLAR.PARAMETERIZED", ("z",),
                          "EPIPOLAR.ZRESIDUAL", True, "EPIPOLAR.USE_CORRECT_NORMALIZE", True,
                          "EPIPOLAR.SHARE_WEIGHTS", True,          # every configs/epipolar/*.yaml of the reference sets it
-                         "EPIPOLAR.SAMPLESIZE", args.samples])
+                         "EPIPOLAR.SAMPLESIZE", samples])
     net = MultiViewPoseModel(cfg).to(dev).eval().to(memory_format=torch.channels_last)
     n = frames * V
-    img = torch.randn(n, 3, args.hw * 4, args.hw * 4, device=dev).contiguous(memory_format=torch.channels_last)
+    P_ref, _ = syn.make_pairs(frames, V, hw * 4, seed=1000, jitter=(0.05, 8.0))
+    img = torch.randn(n, 3, hw * 4, hw * 4, device=dev).contiguous(memory_format=torch.channels_last)
     idx = ring_sources(frames, V, dev)                                                # ring neighbour of each view
 
     def step():
@@ -495,7 +499,8 @@ def end_to_end(args, dev, P_ref, P_src, frames, V):
         step()
     torch.cuda.synchronize()
     ms = (time.perf_counter() - t0) / reps * 1e3
-    return {"ms_per_step": ms, "views_per_s": n / (ms * 1e-3), "model": "epipolarposeR-50 random init, fp32, eval",
+    return {"ms_per_step": ms, "views_per_s": n / (ms * 1e-3), "views": n, "image": hw * 4,
+            "model": "%s random init, fp32, eval" % body,
             "note": "trunk once per view (the reference runs it twice per pair)"}
 
 

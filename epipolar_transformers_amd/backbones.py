@@ -21,7 +21,7 @@ import torch
 from torch import nn
 import torch.nn.functional as F
 
-from .config import amd_knob, get_cfg
+from .config import get_cfg
 from .epipolar import Epipolar
 
 
@@ -194,22 +194,10 @@ class PoseResNet(nn.Module):
     def trunk(self, x):
         """Image -> the pre-fusion feature map of resnet.py:406 (ResNet stages + the three deconvolutions), without
         any fusion: what `forward(x, other_inputs=None)` returns as element 0 (model.py:244 calls it for that).
-
-        In eval mode a large batch goes through in slices whose largest activation (conv1's output) stays below
-        EPIPOLAR_AMD.TRUNK_MAX_ACT_BYTES (default 512 MiB): exact (the BN layers use their running statistics), and it
-        keeps MIOpen on its tuned fp32 solvers -- with 128 images of 384 x 384 in ONE call (1.2 GB activations) it falls
-        back to `naive_conv_ab_nonpacked_*` for two dozen layers, 100 ms each (profiles/r03_config4_kernel_stats.csv:
-        83 % of the end-to-end leg).  Training keeps one pass: the batch statistics must span the whole batch."""
+        (Round 4 tried slicing large eval batches -- 128 images of 384 x 384 are 1.2 GB of activations per layer -- on the
+        suspicion that MIOpen leaves its tuned fp32 solvers there: it does not, one pass is 4 % faster, scripts/e2e_shapes.py.)"""
         if x.is_cuda:
             x = x.contiguous(memory_format=torch.channels_last)             # NHWC all the way to the fused kernel
-        n = x.shape[0]
-        per_image = 64 * ((x.shape[2] + 1) // 2) * ((x.shape[3] + 1) // 2) * x.element_size()
-        step = max(1, int(amd_knob(self.cfg, "TRUNK_MAX_ACT_BYTES", 512 << 20)) // per_image)
-        if self.training or n <= step:
-            return self._trunk(x)
-        return torch.cat([self._trunk(x[a:a + step]) for a in range(0, n, step)])
-
-    def _trunk(self, x):
         x = self.layer1(self.maxpool(self.relu(self.bn1(self.conv1(x)))))
         return self.deconv_layers(self.layer4(self.layer3(self.layer2(x))))
 
