@@ -32,7 +32,7 @@ ET_VARIANT_TILE_CLASSIC = 65536
 ET_VARIANT_WS_V2 = 131072
 ET_VARIANT_WS_SETPRIO = 262144
 ET_VARIANT_TILE_EXACT = 524288
-ET_ABI_VERSION = 10
+ET_ABI_VERSION = 11
 ET_GENERAL_POOLING = 1
 ET_GENERAL_PRIOR_MUL = 2
 ET_GENERAL_COSINE = 4
@@ -71,6 +71,7 @@ _SIGNATURES = {
     "et_epipolar_forward_workspace_stats_offset": (ctypes.c_size_t, [_D]),
     "et_epipolar_forward_workspace_error_offset": (ctypes.c_size_t, [_D]),
     "et_epipolar_forward_tiled": (ctypes.c_int, [_D] + [_P] * 12 + [ctypes.c_size_t, _P]),
+    "et_epipolar_forward_fused": (ctypes.c_int, [_D] + [_P] * 12 + [ctypes.c_int32, _P, ctypes.c_size_t, _P]),
     "et_epipolar_backward_tiled_workspace_bytes": (ctypes.c_size_t, [_D]),
     "et_epipolar_backward_tiled": (ctypes.c_int, [_D, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, ctypes.c_size_t, _P]),
     "et_epipolar_backward_tiled_attn": (ctypes.c_int, [_D, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, ctypes.c_size_t, _P]),

@@ -65,6 +65,10 @@ constexpr int kWavesPerBlock = 4;
 constexpr int kPixPerWave = 4;
 constexpr int kPixPerBlock = kWavesPerBlock * kPixPerWave;  // 16 consecutive pixels
 constexpr int kXcds = 8;
+// uint32 words of the packed weight of the residual GEMM (residual_gemm_pack_kernel): [k-step][n-block][hi|lo][lane][16 B];
+// the float behind them is 1 / (the power-of-two scale the weight was split under).  Read by residual_gemm_kernel and by the
+// fused forward (third GEMM of the persistent kernel).
+constexpr int kRgPackedWords = 16 * 8 * 2 * 64 * 4;
 
 struct FwdParams {
     EtLayerDesc d;

@@ -7,6 +7,55 @@ namespace {
 #include "kernels_forward_tile_ws.inc"  // epipolar_fwd_tile_ws_kernel (warp-specialised, persistent): the default
 #include "kernels_source_planes.inc"    // source_planes_kernel (the source maps as split-fp16 planes, once per call)
 #include "kernels_forward_tile_ws2.inc" // epipolar_fwd_tile_ws2_kernel (pre-split source planes; ET_VARIANT_WS_V2 only)
+
+// x rows of the tiles the fused persistent kernel handed to the overflow list (their `out` rows come from the one-block-per-
+// tile kernel): x = feat_ref + bias + out . Wf^T in plain fp32, one block per tile, thread n = output channel n.  Wf is
+// rebuilt from the packed fragments (hi + lo: the 22 significant bits the matrix-core path multiplies with).  Rare path
+// (normally zero tiles): written for clarity, not speed.
+__global__ __launch_bounds__(256) void residual_rows_list_kernel(const int *__restrict__ perm, const int *__restrict__ tile_list,
+                                                                 const int *__restrict__ tile_count, int tiles_per_pair, int HW,
+                                                                 const float *__restrict__ out, const float *__restrict__ feat,
+                                                                 const unsigned *__restrict__ packed, const float *__restrict__ bias,
+                                                                 float *__restrict__ x)
+{
+    __shared__ float s_out[kTilePix][256];
+    __shared__ int s_px[kTilePix];
+    const int nch = threadIdx.x;                      // output channel
+    const float inv_w = reinterpret_cast<const float *>(packed)[kRgPackedWords];
+    const int count = *tile_count;
+    for (int e = blockIdx.x; e < count; e += gridDim.x) {
+        const int tile = tile_list[e];
+        const size_t base = (size_t)(tile / tiles_per_pair) * HW * 256;
+        __syncthreads();
+        if (threadIdx.x < kTilePix) s_px[threadIdx.x] = perm[(size_t)tile * kTilePix + threadIdx.x];
+        __syncthreads();
+        for (int m = 0; m < kTilePix; ++m) s_out[m][nch] = s_px[m] >= 0 ? out[base + (size_t)s_px[m] * 256 + nch] : 0.f;
+        __syncthreads();
+        float acc[kTilePix];
+#pragma unroll
+        for (int m = 0; m < kTilePix; ++m) acc[m] = 0.f;
+        // fragment (ks, nb, term, lane): lane (n & 31, kg) holds Wf[n][16 ks + 8 kg .. + 7] (residual_gemm_pack_kernel)
+        const int nb = nch >> 5;
+        for (int ks = 0; ks < 16; ++ks)
+            for (int kg = 0; kg < 2; ++kg) {
+                const f16x8 *frag = reinterpret_cast<const f16x8 *>(packed) + ((size_t)(ks * 8 + nb) * 2) * 64 + (kg * 32 + (nch & 31));
+                const f16x8 hi = frag[0], lo = frag[64];
+#pragma unroll
+                for (int jj = 0; jj < 8; ++jj) {
+                    const float w = ((float)hi[jj] + (float)lo[jj]) * inv_w;
+                    const int k = ks * 16 + kg * 8 + jj;
+#pragma unroll
+                    for (int m = 0; m < kTilePix; ++m) acc[m] = fmaf(s_out[m][k], w, acc[m]);
+                }
+            }
+        const float b = bias[nch];
+        for (int m = 0; m < kTilePix; ++m)
+            if (s_px[m] >= 0) {
+                const size_t o = base + (size_t)s_px[m] * 256 + nch;
+                x[o] = (feat[o] + b) + acc[m];
+            }
+    }
+}
 }  // namespace
 #include "et_tile_host.h"
 
@@ -155,6 +204,10 @@ int et_epipolar_forward_tiled(const EtLayerDesc *desc, const float *xs, const fl
         wp.scales = w.scales;
         wp.segs = w.segs;
         wp.band = w.band;
+        wp.packed_w = nullptr;
+        wp.bias = nullptr;
+        wp.x = nullptr;
+        wp.err = w.err;
         wp.setprio = (desc->variant & ET_VARIANT_WS_SETPRIO) ? 1 : 0;
 #ifdef ET_WS_PROFILE
         wp.prof = g_ws_prof;
@@ -196,6 +249,99 @@ int et_epipolar_forward_tiled(const EtLayerDesc *desc, const float *xs, const fl
 #undef ET_TILE
 #undef ET_SET_LDS
     return check_launch("et_epipolar_forward_tiled");
+}
+
+
+// The layer's eval-mode forward as ONE data kernel: sampling + attention (as et_epipolar_forward_tiled) with
+// x = feat_ref + bias + out . Wf^T -- bn(z(out)) + out + feat with the BN folded into z (epipolar.py:250-253, resnet.py:388;
+// what et_residual_gemm computes from `out` in a second pass) -- as a third GEMM of the persistent kernel.
+int et_epipolar_forward_fused(const EtLayerDesc *desc, const float *xs, const float *ys, const float *steps,
+                              const float *cam, const float *feat_ref, const float *feat_src, const void *packed_w,
+                              const float *bias, float *x, float *attn, float *corr_pos, float *out_scratch,
+                              int32_t want_out, void *workspace, size_t workspace_bytes, void *stream)
+{
+    if (int e = validate(desc)) return e;
+    if (!xs || !ys || !steps || !cam || !feat_ref || !feat_src || !packed_w || !bias || !x || !out_scratch)
+        return fail("et_epipolar_forward_fused: NULL pointer");
+    if (reinterpret_cast<uintptr_t>(packed_w) & 15) return fail("et_epipolar_forward_fused: packed weight must be 16-byte aligned");
+    if (!tile_eligible(desc) || !tile_ws_eligible(desc) || tile_ws2_eligible(desc))
+        return fail("et_epipolar_forward_fused: needs the warp-specialised tile kernel (C == 256, maps up to 64 x 64, K <= 64, "
+                    "soft-max on; got C=%d H=%d W=%d K=%d variant=%d): use et_epipolar_forward_tiled + et_residual_gemm",
+                    desc->C, desc->H, desc->W, desc->K, desc->variant);
+    const size_t need = et_epipolar_forward_workspace_bytes(desc);
+    if (!workspace || workspace_bytes < need)
+        return fail("et_epipolar_forward_fused: workspace of %zu bytes is smaller than the %zu required",
+                    workspace ? workspace_bytes : (size_t)0, need);
+    hipStream_t st = (hipStream_t)stream;
+    const int HW = desc->H * desc->W;
+    TileParams tp;
+    FwdParams &p = tp.f;
+    p.d = *desc;
+    p.xs = xs; p.ys = ys; p.steps = steps; p.cam = cam;
+    p.fref = feat_ref; p.fsrc = feat_src;
+    p.out = out_scratch; p.attn = attn; p.corr = corr_pos;
+    p.res_bias = nullptr; p.res_base = nullptr;
+    p.interleave = 0; p.ablate = 0;
+    tp.tiles_per_pair = (HW + kTilePix - 1) / kTilePix;
+    p.blocks_per_pair = tp.tiles_per_pair;
+    const long long total = (long long)tp.tiles_per_pair * desc->N;
+    if (total > 0x7fffffffLL / kTilePix) return fail("grid too large");
+    p.total_blocks = (int)total;
+    tp.hw_words = (HW + 31) / 32;
+    tp.rows_cap = tile_rows_cap(desc);
+    const TileWorkspace w = carve_tile_workspace(workspace, (size_t)total, (size_t)desc->N, (size_t)HW);
+    tp.perm = w.perm;
+    tp.stats = w.stats;
+    tp.tile_list = w.ovf_list;
+    tp.tile_count = w.ovf_count;
+    tp.scales = (desc->variant & ET_VARIANT_TILE_EXACT) ? nullptr : w.scales;
+    int n2 = 64;
+    while (n2 < HW) n2 <<= 1;
+    const size_t lds_sort = (size_t)n2 * sizeof(unsigned long long);
+    const int dev = current_device();
+    ET_GRANT_LDS(tile_order_kernel, lds_sort, dev);
+    hipLaunchKernelGGL(tile_order_kernel, dim3(desc->N), dim3(1024), lds_sort, st, *desc, xs, ys, cam, n2,
+                       tp.tiles_per_pair * kTilePix, w.perm, w.ovf_count, feat_ref, feat_src, w.scales, w.segs, w.band);
+    if (int e = check_launch("et_epipolar_forward_fused(order)")) return e;
+    TileWsParams wp;
+    wp.f = p;
+    wp.f.out = want_out ? out_scratch : nullptr;      // (the persistent kernel writes `out` on request only)
+    wp.perm = w.perm;
+    wp.tiles_per_pair = tp.tiles_per_pair;
+    wp.total_tiles = (int)total;
+    wp.rows_cap = tp.rows_cap;
+    wp.ovf_count = w.ovf_count;
+    wp.ovf_list = w.ovf_list;
+    wp.stats = w.stats;
+    wp.scales = w.scales;
+    wp.segs = w.segs;
+    wp.band = w.band;
+    wp.setprio = 0;
+    wp.prof = nullptr;
+    wp.packed_w = reinterpret_cast<const unsigned *>(packed_w);
+    wp.bias = bias;
+    wp.x = x;
+    wp.err = w.err;
+    const int cus = device_cus(dev);
+    const unsigned grid = (unsigned)(total < cus ? total : cus);
+    const size_t lds_ws = tile_ws_lds_bytes(kTileRowsSmall, desc->H, desc->W);
+    ET_GRANT_LDS((epipolar_fwd_tile_ws_kernel<kTileRowsSmall, 8, true>), lds_ws, dev);
+    hipLaunchKernelGGL((epipolar_fwd_tile_ws_kernel<kTileRowsSmall, 8, true>), dim3(grid), dim3((kWsMatrixWaves + 8) * kWave),
+                       lds_ws, st, wp);
+    if (int e = check_launch("et_epipolar_forward_fused(ws)")) return e;
+    // the tiles it left over: `out` rows one block per tile, then their x rows
+    const int kpl = 1;
+    const int rows = tile_rows(desc);
+    const size_t lds = (size_t)(fwd_tile_array_floats(rows) + rows + kTilePix + 48 + kTilePix * 4) * 4 +
+                       (size_t)tp.hw_words * 8 + (kpl == 1 ? (size_t)kTilePix * kWave * 8 : 0);
+    const unsigned lgrid = (unsigned)(total < 2LL * cus ? total : 2LL * cus);
+    ET_GRANT_LDS((epipolar_fwd_tile_list_kernel<1, kTileRowsSmall>), lds, dev);
+    hipLaunchKernelGGL((epipolar_fwd_tile_list_kernel<1, kTileRowsSmall>), dim3(lgrid), dim3(256), lds, st, tp);
+    if (int e = check_launch("et_epipolar_forward_fused(list)")) return e;
+    hipLaunchKernelGGL(residual_rows_list_kernel, dim3((unsigned)(total < cus ? total : cus)), dim3(256), 0, st, w.perm,
+                       w.ovf_list, w.ovf_count, tp.tiles_per_pair, HW, out_scratch, feat_ref,
+                       reinterpret_cast<const unsigned *>(packed_w), bias, x);
+    return check_launch("et_epipolar_forward_fused(list rows)");
 }
 
 }  // extern "C"

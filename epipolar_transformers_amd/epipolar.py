@@ -430,9 +430,11 @@ class Epipolar(nn.Module):
         return finalout, corr_pos, attn, sample_locs
 
     def forward_fused(self, feat1, feat2, P1, P2, camera=None, other_camera=None):
-        """forward + `ret + feat` (resnet.py:388).  In eval mode the whole epilogue is ONE GEMM kernel:
-        x = feat + bf + out @ Wf^T (`ops.residual_gemm` for the 256-channel head; other widths: the fused kernel
-        emits feat + bf and a library GEMM accumulates into it).  Returns (x, corr_pos, depth, None)."""
+        """forward + `ret + feat` (resnet.py:388).  In eval mode the whole epilogue is ONE GEMM, x = feat + bf + out @ Wf^T:
+        for the 256-channel head on maps up to 64 x 64 (K <= 64) a third GEMM INSIDE the persistent forward kernel
+        (`ops.forward_fused_nhwc`: `out` never goes through HBM), for the other 256-channel shapes `ops.residual_gemm` behind
+        the forward; other widths: the fused kernel emits feat + bf and a library GEMM accumulates into it.
+        Returns (x, corr_pos, depth, None)."""
         self._check_mode(None, None, None)
         if not self._fused_mode():
             fin, corr_pos, attn, _ = self.forward(feat1, feat2, P1, P2, camera=camera, other_camera=other_camera)
@@ -446,8 +448,13 @@ class Epipolar(nn.Module):
         if "z" in self.cfg.EPIPOLAR.PARAMETERIZED and ref.shape[-1] == 256:
             # x = feat + bf + out . Wf^T in ONE kernel behind the fused forward (no res_base round trip through HBM)
             packed, bf = self._packed_z()
-            out, attn, corr_pos = ops.forward_nhwc(self.layer_spec(), ref, src, cam)
-            x = ops.residual_gemm(out, packed, bf, ref)
+            spec = self.layer_spec()
+            if bool(amd_knob(self.cfg, "FUSED_GEMM3", True)) and ops.fused_layer_applies(spec, 256, ref.shape[0]):
+                # ... inside the persistent kernel, as a third GEMM on the tile's out rows (ops.forward_fused_nhwc)
+                x, attn, corr_pos = ops.forward_fused_nhwc(spec, ref, src, cam, packed, bf)
+            else:
+                out, attn, corr_pos = ops.forward_nhwc(spec, ref, src, cam)
+                x = ops.residual_gemm(out, packed, bf, ref)
         elif "z" in self.cfg.EPIPOLAR.PARAMETERIZED:
             wt, bf = self._folded_z()
             out, attn, corr_pos, base = ops.forward_nhwc(self.layer_spec(), ref, src, cam, res_bias=bf,

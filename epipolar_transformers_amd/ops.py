@@ -269,6 +269,52 @@ def forward_nhwc(spec: LayerSpec, ref: torch.Tensor, src: torch.Tensor, cam: tor
     return out, attn, corr
 
 
+def fused_layer_applies(spec: LayerSpec, c: int, n: int = 1) -> bool:
+    """True when et_epipolar_forward_fused covers this shape (the warp-specialised tile kernel: C == 256, maps up to
+    64 x 64, K <= 64, soft-max on, no variant bit that leaves that kernel)."""
+    allowed = _lib.ET_VARIANT_TILE_SPLIT | _lib.ET_VARIANT_WS_SETPRIO
+    if not (c == 256 and 2 <= spec.W <= 64 and spec.H <= 64 and spec.K <= 64 and spec.softmax_enabled and
+            (spec.variant & ~allowed) == 0):
+        return False
+    d = spec.desc(n, c)
+    return int(_lib.load().et_epipolar_forward_workspace_bytes(ctypes.byref(d))) > 0
+
+
+def forward_fused_nhwc(spec: LayerSpec, ref: torch.Tensor, src: torch.Tensor, cam: torch.Tensor, packed: torch.Tensor,
+                       bias: torch.Tensor, want_attn=True, want_corr=True, want_out=False, workspace=None):
+    """The eval-mode layer as one data kernel (et_epipolar_forward_fused): returns x = ref + bias + out @ Wf^T (N,H,W,C),
+    attn (N,K,H,W)|None, corr_pos (N,H,W,2)|None [, out when want_out].  `packed`: residual_gemm_pack(Wf)."""
+    for t, nm in ((ref, "feat_ref"), (src, "feat_src"), (cam, "cam"), (bias, "bias")):
+        _require_gpu(t, nm)
+    if not packed.is_cuda or packed.dtype != torch.uint8:
+        raise TypeError("packed must be the uint8 device buffer residual_gemm_pack returns")
+    n, h, w, c = ref.shape
+    if (h, w) != (spec.H, spec.W) or src.shape != ref.shape or c != 256:
+        raise ValueError("feature maps %s / %s do not match the layer's %dx%d x 256" % (tuple(ref.shape), tuple(src.shape), spec.H, spec.W))
+    if cam.shape != (n, _lib.ET_CAM_STRIDE) or not cam.is_contiguous():
+        raise ValueError("cam must be a contiguous (N,%d) tensor" % _lib.ET_CAM_STRIDE)
+    assert ref.is_contiguous() and src.is_contiguous() and bias.is_contiguous() and bias.numel() == c
+    xs, ys, steps = spec.constants(ref.device)
+    x = _empty(None, like=ref)
+    # scratch for the rows of overflow tiles (normally none are written: the pages are never touched); the caching
+    # allocator hands the same block back call after call
+    out = _empty(None, like=ref) if want_out else torch.empty_like(ref)
+    attn = _empty((n, spec.K, h, w), device=ref.device) if want_attn else None
+    corr = _empty((n, h, w, 2), device=ref.device) if want_corr else None
+    d = spec.desc(n, c)
+    lib = _lib.load()
+    ws_bytes = int(lib.et_epipolar_forward_workspace_bytes(ctypes.byref(d)))
+    with torch.cuda.device(ref.device):
+        ws = workspace if workspace is not None else _workspace(ref.device, max(ws_bytes, 1), "fwd")
+        _lib.check(lib.et_epipolar_forward_fused(ctypes.byref(d), _ptr(xs), _ptr(ys), _ptr(steps), _ptr(cam), _ptr(ref),
+                                                 _ptr(src), _ptr(packed), _ptr(bias), _ptr(x), _ptr(attn), _ptr(corr),
+                                                 _ptr(out), 1 if want_out else 0, _ptr(ws), ctypes.c_size_t(ws.numel()),
+                                                 _stream(ref)), "et_epipolar_forward_fused")
+        if POISON_OUTPUTS:
+            check_tile_errors(workspace=ws)
+    return (x, attn, corr, out) if want_out else (x, attn, corr)
+
+
 _workspaces = {}
 
 

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define ET_ABI_VERSION 10
+#define ET_ABI_VERSION 11
 
 /* Static description of one layer call: the cfg keys the reference reads in
  * Epipolar.__init__ (epipolar.py:12-54) and at call time (epipolar.py:303-311,
@@ -140,10 +140,11 @@ int et_epipolar_forward(const EtLayerDesc *desc, const float *xs, const float *y
  *               64-word header -- word 0 the overflow-tile count, word 1 a STICKY int32 error word
  *               (et_epipolar_forward_workspace_error_offset(desc) = 4 bytes in, whatever the shape, so
  *               that a workspace reused across shapes keeps ONE error word: the kernels only ever OR
- *               bits into it; bit 0: a wave of a persistent kernel gave up waiting at an internal
- *               barrier -- the results of that call are invalid.  Only the ET_VARIANT_WS_V2 kernel has
- *               such a barrier; the default kernel's waves never wait on each other outside the
- *               hardware barrier.  The library never synchronises, so the caller reads the word when
+ *               bits into it; bit 0 / bit 1: a wave of a persistent kernel gave up waiting at an
+ *               internal barrier -- the results of that call are invalid.  Such barriers exist in the
+ *               ET_VARIANT_WS_V2 kernel (bit 0) and in front of the third GEMM of
+ *               et_epipolar_forward_fused (bit 1); the default kernel's waves never wait on each other
+ *               outside the hardware barrier.  The library never synchronises, so the caller reads the word when
  *               it synchronises anyway: ops.check_tile_errors in the Python binding) -- followed by
  *               the per-pair pixel order, the overflow-tile list, per-pair scales, the epipolar
  *               segments and one base line per tile (with ET_VARIANT_WS_V2 also the source planes,
@@ -262,6 +263,25 @@ size_t et_residual_gemm_packed_bytes(void);
 int et_residual_gemm_pack(const float *wf, void *packed, void *stream);
 int et_residual_gemm(int64_t num_pixels, int32_t C, const float *out, const float *feat, const void *packed,
                      const float *bias, float *x, void *stream);
+
+/* The whole eval-mode layer as ONE data kernel (ABI 11): the sampling + attention of et_epipolar_forward_tiled with
+ *     x = feat_ref + bias + out . Wf^T
+ * -- `bn(z(out)) + out` (epipolar.py:250-253) and the backbone's `ret + feat` (resnet.py:388) with the eval-mode BN
+ * folded into z, i.e. what et_residual_gemm computes from `out` in a second pass -- as a third GEMM of the persistent
+ * kernel, on the tile's 32 `out` rows while they are still on chip: `out` is neither written nor re-read (1.07 GB less
+ * traffic and one launch less per forward at Config 2).  Applies where the warp-specialised kernel does (C == 256, maps
+ * up to 64 x 64, K <= 64, soft-max on, no ET_VARIANT_TILE_CLASSIC / _WS_V2); otherwise the call fails and
+ * et_epipolar_forward_tiled + et_residual_gemm is the path.
+ *   packed_w    : Wf laid out by et_residual_gemm_pack;   bias : (256)
+ *   x           : (N,H,W,256)                              attn / corr_pos : as et_epipolar_forward, nullable
+ *   out_scratch : (N,H,W,256), required: the rows of tiles the persistent kernel hands to its overflow list (a row set
+ *                 beyond its arrays, a source value beyond fp16's range) are produced there by the one-block-per-tile
+ *                 kernel and their x rows by a small follow-up kernel; with want_out != 0 every row of `out` is written.
+ *   workspace   : as et_epipolar_forward_tiled (same size, same sticky error word). */
+int et_epipolar_forward_fused(const EtLayerDesc *desc, const float *xs, const float *ys, const float *steps,
+                              const float *cam, const float *feat_ref, const float *feat_src, const void *packed_w,
+                              const float *bias, float *x, float *attn, float *corr_pos, float *out_scratch,
+                              int32_t want_out, void *workspace, size_t workspace_bytes, void *stream);
 
 /* Peak finder of the pose head: find_tensor_peak_batch (modeling/backbones/basic_batch.py:17-63), which
  * PoseResNet.forward calls once per sample in a Python loop (resnet.py:424-430).  One launch for all maps.

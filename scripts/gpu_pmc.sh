@@ -36,7 +36,7 @@ with open(out + "_summary.txt", "w") as fh:
         line = "%-62s %-32s n=%d mean=%.6g" % (kn, cn, len(vals), sum(vals) / len(vals))
         print(line); fh.write(line + "\n")
 import json
-want_bwd = os.environ.get("PROF_KERNEL", "fwd") != "fwd"                     # (the backward run launches one forward for the attention)
+want_bwd = os.environ.get("PROF_KERNEL", "fwd") == "bwd"                     # (the backward run launches one forward for the attention)
 main = ([kn for kn, _ in agg if want_bwd and "bwd" in kn] + [kn for kn, _ in agg if "ws_kernel" in kn] +
         [kn for kn, _ in agg if "bwd_tile" in kn or "fwd_tile_kernel" in kn] +
         [kn for kn, _ in agg if kn.startswith("epipolar")] + [None])[0]          # the dominant kernel of the run
@@ -44,7 +44,7 @@ get = lambda name: next((sum(v) / len(v) for (kn, cn), v in agg.items() if cn ==
 if get("FETCH_SIZE") is not None and get("WRITE_SIZE") is not None:
     json.dump({"C": 256, "H": int(os.environ.get("PROF_HW", 64)), "W": int(os.environ.get("PROF_HW", 64)),
                "K": int(os.environ.get("PROF_K", 64)), "pairs": 128, "kernel": main,
-               "variant": int(os.environ.get("PROF_VARIANT", 0)), "FETCH_SIZE_KB": get("FETCH_SIZE"),
+               "variant": int(os.environ.get("PROF_VARIANT", 0)), "which": os.environ.get("PROF_KERNEL", "fwd"), "FETCH_SIZE_KB": get("FETCH_SIZE"),
                "WRITE_SIZE_KB": get("WRITE_SIZE"), "TCC_HIT_sum": get("TCC_HIT_sum"), "TCC_MISS_sum": get("TCC_MISS_sum"),
                "VALUBusy": get("VALUBusy"), "SQ_INSTS_VALU": get("SQ_INSTS_VALU")},
               open(out + "_pmc.json", "w"), indent=1)

@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""Launch the fused forward (default) or backward kernel a few times on the
+"""Launch the fused forward (default), the one-kernel layer (PROF_KERNEL=fused) or the backward kernel a few times on the
 Config-2 workload -- the target of rocprofv3 --pmc passes (scripts/gpu_pmc.sh)."""
 import os
 import sys
@@ -20,10 +20,15 @@ ref = torch.randn(128, H, H, C, device=dev, generator=g).relu_()
 src = torch.randn(128, H, H, C, device=dev, generator=g).relu_()
 cam = camera.pair_algebra(P1, P2).to(dev)
 spec = ops.LayerSpec(H=H, W=H, K=K, variant=variant)
-attn = ops.forward_nhwc(spec, ref, src, cam)[1] if which != "fwd" else None      # what autograd hands the backward
+attn = ops.forward_nhwc(spec, ref, src, cam)[1] if which == "bwd" else None      # what autograd hands the backward
+if which == "fused":       # the one-kernel layer: sampling + attention + z / BN / residual GEMM
+    packed = ops.residual_gemm_pack(torch.randn(C, C, device=dev, generator=g) * 0.05 + torch.eye(C, device=dev))
+    bias = torch.randn(C, device=dev, generator=g)
 for _ in range(int(os.environ.get("PROF_REPS", 3))):
     if which == "fwd":
         ops.forward_nhwc(spec, ref, src, cam)
+    elif which == "fused":
+        ops.forward_fused_nhwc(spec, ref, src, cam, packed, bias)
     else:
         ops.backward_nhwc(spec, ref, src, cam, ref, attn=attn)
 torch.cuda.synchronize()

@@ -1,0 +1,152 @@
+"""et_epipolar_forward_fused: the eval-mode layer as ONE data kernel -- the persistent sample + attention kernel with
+x = feat_ref + bias + out . Wf^T (bn(z(out)) + out + feat, epipolar.py:250-253 + resnet.py:388, BN folded into z) as a third
+GEMM on the tile's out rows -- against
+
+  * the two-kernel path it replaces (et_epipolar_forward_tiled + et_residual_gemm): attention / corr_pos bit for bit,
+    x to fp32-GEMM-level error;
+  * float64 of the epilogue applied to `out` (the bound of tests/test_gpu_parity.py::test_residual_gemm_abi);
+  * the C oracle's forward + the reference's own op sequence for the epilogue (conv1x1 + eval batch-norm + two adds);
+  * with tiles forced onto the overflow list (row-set capacity 64; a source value beyond fp16's range): their `out` rows come
+    from the one-block-per-tile kernel and their x rows from the follow-up kernel.
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+C = 256
+
+
+@pytest.fixture(scope="module")
+def env():
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    from epipolar_transformers_amd import _lib, camera, ops
+
+    _lib.load()
+    return _lib, camera, ops
+
+
+def _inputs(n, h, seed, outlier=False):
+    from epipolar_transformers_amd import synthetic as syn
+
+    P1, P2 = syn.make_pairs((n + 3) // 4, 4, 4 * h, seed=seed, jitter=(0.05, 8.0))
+    P1, P2 = P1[:n], P2[:n]
+    f1, f2 = syn.make_features(n, C, h, h, seed=seed + 1)
+    if outlier:
+        f2[n - 1, 100, 5, 6] = 4.0e4          # beyond fp16 under the estimated scale: those tiles are redone in exact fp32
+    g = torch.Generator().manual_seed(seed + 2)
+    wf = torch.randn(C, C, generator=g) * 0.05 + torch.eye(C)
+    bias = torch.randn(C, generator=g)
+    return P1, P2, f1, f2, wf, bias
+
+
+def _bound(out, wf, want):
+    return 4e-6 * (out.double().abs() @ wf.double().abs().t()) + 3e-7 * (want.abs() + 1)
+
+
+@pytest.mark.parametrize("n,h,k,variant,outlier", [(8, 64, 64, 0, False), (5, 48, 33, 0, False), (4, 16, 16, 0, False),
+                                                   (4, 16, 16, 32768, False), (4, 64, 64, 0, True), (3, 33, 20, 0, False)],
+                         ids=["64x64-K64", "48x48-K33", "16x16-K16", "16x16-K16-overflow-tiles", "64x64-K64-fp16-guard", "33x33-K20"])
+def test_fused_layer_vs_two_kernels_and_float64(env, n, h, k, variant, outlier):
+    _lib, camera, ops = env
+    P1, P2, f1, f2, wf, bias = _inputs(n, h, seed=50 + h + k, outlier=outlier)
+    spec = ops.LayerSpec(H=h, W=h, K=k, variant=variant)
+    assert ops.fused_layer_applies(spec, C, n)
+    ref, src = ops.to_nhwc(f1.cuda()), ops.to_nhwc(f2.cuda())
+    cam = camera.pair_algebra(P1, P2).cuda()
+    wf_d, bias_d = wf.cuda(), bias.cuda()
+    packed = ops.residual_gemm_pack(wf_d)
+    # the two-kernel path
+    out2, attn2, corr2 = ops.forward_nhwc(spec, ref, src, cam)
+    x2 = ops.residual_gemm(out2, packed, bias_d, ref)
+    # one kernel
+    ws = ops.tile_workspace(spec, n, C, ref.device)
+    x1, attn1, corr1, out1 = ops.forward_fused_nhwc(spec, ref, src, cam, packed, bias_d, want_out=True, workspace=ws)
+    torch.cuda.synchronize()
+    ops.check_tile_errors(workspace=ws)
+    assert torch.isfinite(x1).all()
+    assert torch.equal(attn1, attn2) and torch.equal(corr1, corr2) and torch.equal(out1, out2)
+    want = out2.double().reshape(-1, C) @ wf_d.double().t() + bias_d.double() + ref.double().reshape(-1, C)
+    err = (x1.double().reshape(-1, C) - want).abs()
+    bound = _bound(out2.reshape(-1, C), wf_d, want)
+    assert (err <= bound).all(), (err / bound).max().item()
+    assert (x1 - x2).abs().max().item() <= 2e-5 * max(1.0, x2.abs().max().item())
+    # without `out` (the product path): same x, and the scratch is only touched for overflow tiles
+    x3, attn3, corr3 = ops.forward_fused_nhwc(spec, ref, src, cam, packed, bias_d)
+    assert torch.equal(x3, x1) and torch.equal(attn3, attn1) and torch.equal(corr3, corr1)
+    if variant or outlier:
+        base = (-ws.data_ptr()) % 256
+        assert int(ws[base:base + 4].view(torch.int32).item()) > 0, "the case was meant to put tiles on the overflow list"
+
+
+def test_fused_layer_vs_oracle_and_reference_epilogue(env, oracle_mod):
+    """Forward of the C oracle, then the reference's own op sequence for bn(z(out)) + out + feat in eval mode."""
+    _lib, camera, ops = env
+    n, h, k = 4, 32, 24
+    P1, P2, f1, f2, _, _ = _inputs(n, h, seed=91)
+    g = torch.Generator().manual_seed(7)
+    zw, zb = torch.randn(C, C, 1, 1, generator=g) * 0.05, torch.randn(C, generator=g) * 0.1
+    gamma, beta = 1 + 0.1 * torch.randn(C, generator=g), 0.1 * torch.randn(C, generator=g)
+    mean, var = 0.1 * torch.randn(C, generator=g), 0.5 + torch.rand(C, generator=g)
+    cam = camera.pair_algebra(P1, P2)
+    want = oracle_mod.forward(oracle_mod.LayerSpec(h, h, k), f1, f2, None, None, cam=cam.numpy())
+    _, want_x = oracle_mod.epilogue(want["out"], f1.numpy(), zw.numpy(), zb.numpy(), gamma.numpy(), beta.numpy(), mean.numpy(),
+                                    var.numpy(), training=False)
+    s = gamma / torch.sqrt(var + 1e-5)
+    wf = (zw.view(C, C) * s[:, None] + torch.eye(C)).cuda()
+    bf = (zb * s + beta - mean * s).cuda()
+    x, attn, corr = ops.forward_fused_nhwc(ops.LayerSpec(H=h, W=h, K=k), ops.to_nhwc(f1.cuda()), ops.to_nhwc(f2.cuda()), cam.cuda(),
+                                           ops.residual_gemm_pack(wf), bf)
+    x = x.permute(0, 3, 1, 2).cpu().numpy()
+    assert np.abs(attn.cpu().numpy() - want["attn"]).max() <= 1e-5
+    assert np.abs(x - want_x.numpy()).max() <= 1e-4
+
+
+def test_fused_layer_is_what_the_module_runs_in_eval(env):
+    """Epipolar.forward_fused (what PoseResNet._fuse calls) takes the one-kernel path for the 256-channel head and matches the
+    two-kernel path it replaces (EPIPOLAR_AMD.FUSED_GEMM3 False)."""
+    from epipolar_transformers_amd import default_cfg
+    from epipolar_transformers_amd.epipolar import Epipolar
+
+    _lib, camera, ops = env
+    h, k = 32, 16
+    P1, P2, f1, f2, _, _ = _inputs(4, h, seed=17)
+    outs = []
+    for fused in (True, False):
+        cfg = default_cfg()
+        cfg.merge_from_list(["KEYPOINT.HEATMAP_SIZE", (h, h), "KEYPOINT.NFEATS", C, "EPIPOLAR.SAMPLESIZE", k, "EPIPOLAR.ATTENTION", "avg",
+                             "EPIPOLAR.PARAMETERIZED", ("z",), "EPIPOLAR.ZRESIDUAL", True, "EPIPOLAR.USE_CORRECT_NORMALIZE", True,
+                             "DATASETS.IMAGE_SIZE", (4 * h, 4 * h), "EPIPOLAR_AMD.FUSED_GEMM3", fused])
+        torch.manual_seed(3)
+        mod = Epipolar(cfg=cfg).cuda().eval()
+        with torch.no_grad():
+            mod.bn.weight.normal_(1, 0.1)
+            mod.bn.bias.normal_(0, 0.1)
+            mod.bn.running_mean.normal_(0, 0.1)
+            mod.bn.running_var.uniform_(0.5, 1.5)
+            calls = []
+            keep = ops.forward_fused_nhwc
+            ops.forward_fused_nhwc = lambda *a, **kw: (calls.append(1), keep(*a, **kw))[1]
+            try:
+                outs.append(mod.forward_fused(f1.cuda(), f2.cuda(), P1, P2))
+            finally:
+                ops.forward_fused_nhwc = keep
+            assert bool(calls) == fused
+    (xa, ca, aa, _), (xb, cb, ab, _) = outs
+    assert torch.equal(ca, cb) and torch.equal(aa, ab)
+    assert (xa - xb).abs().max().item() <= 2e-5 * max(1.0, xb.abs().max().item())
+
+
+def test_fused_entry_refuses_shapes_of_the_other_kernels(env):
+    _lib, camera, ops = env
+    assert not ops.fused_layer_applies(ops.LayerSpec(H=96, W=96, K=64), C, 2)
+    assert not ops.fused_layer_applies(ops.LayerSpec(H=64, W=64, K=128), C, 2)
+    assert not ops.fused_layer_applies(ops.LayerSpec(H=64, W=64, K=64, softmax_enabled=False), C, 2)
+    assert not ops.fused_layer_applies(ops.LayerSpec(H=64, W=64, K=64), 128, 2)
+    assert not ops.fused_layer_applies(ops.LayerSpec(H=64, W=64, K=64, variant=_lib.ET_VARIANT_TILE_CLASSIC), C, 2)
+    spec = ops.LayerSpec(H=96, W=96, K=64)
+    t = torch.zeros(1, 96, 96, C, device="cuda")
+    with pytest.raises(_lib.EpipolarAmdError):
+        ops.forward_fused_nhwc(spec, t, t, torch.zeros(1, 27, device="cuda"), ops.residual_gemm_pack(torch.eye(C, device="cuda")),
+                               torch.zeros(C, device="cuda"))
