@@ -16,13 +16,20 @@ src = torch.randn(128, H, H, C, device=dev, generator=g).relu_()
 cam = camera.pair_algebra(P1, P2).to(dev)
 spec = ops.LayerSpec(H=H, W=H, K=K)
 ws = ops.tile_workspace(spec, 128, C, dev)
+fused = os.environ.get("AB_FUSED") == "1"
+if fused:
+    packed = ops.residual_gemm_pack(torch.randn(C, C, device=dev, generator=g) * 0.05 + torch.eye(C, device=dev))
+    bias = torch.randn(C, device=dev, generator=g)
+    fwd = lambda: ops.forward_fused_nhwc(spec, ref, src, cam, packed, bias, workspace=ws)
+else:
+    fwd = lambda: ops.forward_nhwc(spec, ref, src, cam, workspace=ws)
 for _ in range(5):
-    ops.forward_nhwc(spec, ref, src, cam, workspace=ws)
+    fwd()
 ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(40)]
 torch.cuda.synchronize()
 for a, b in ev:
     a.record()
-    ops.forward_nhwc(spec, ref, src, cam, workspace=ws)
+    fwd()
     b.record()
 torch.cuda.synchronize()
 t = sorted(a.elapsed_time(b) for a, b in ev)
@@ -30,6 +37,10 @@ base = (-ws.data_ptr()) % 256
 ovf = int(ws[base:base + 4].view(torch.int32).item())
 o, a_, c_ = ops.forward_nhwc(spec, ref[:8], src[:8], cam[:8])
 o2, a2, c2 = ops.forward_nhwc(ops.LayerSpec(H=H, W=H, K=K, variant=_lib.ET_VARIANT_NO_TILE), ref[:8], src[:8], cam[:8])
+if fused:       # x against the two-kernel path
+    xo = ops.residual_gemm(ops.forward_nhwc(spec, ref[:8], src[:8], cam[:8])[0], packed, bias, ref[:8])
+    xf = ops.forward_fused_nhwc(spec, ref[:8], src[:8], cam[:8], packed, bias)[0]
+    label += "  (fused; x vs two kernels %.1e)" % (xf - xo).abs().max().item()
 print("%-28s forward call %.4f ms (min %.4f, p90 %.4f)  overflow tiles %d  | vs per-pixel: out %.2e attn %.2e corr mismatch %.5f"
       % (label, sum(t) / len(t), t[0], t[int(0.9 * len(t))], ovf, (o - o2).abs().max().item(), (a_ - a2).abs().max().item(),
          (c_ != c2).any(-1).float().mean().item()), flush=True)
