@@ -439,10 +439,10 @@ def main():
     ops.check_tile_errors()                  # the sticky device-side error word of the tile forward (synchronises)
     if rank == 0 and not args.no_other_configs and (V, frames, C, H, K) == (4, 32, 256, 64, 64):
         del gout, attn_fwd
-        result["extra"]["config4"] = other_config(dev, hw=96, samples=64, views=4, frames=8,
-                                                  name="configs[3] head: 96x96, K=64 (ResNet-152 384x384), 32 pairs")
-        result["extra"]["config5"] = other_config(dev, hw=128, samples=128, views=8, frames=2,
-                                                  name="configs[4] shape: 128x128, K=128 (8 views, 512x512), 16 pairs")
+        result["extra"]["config4"] = other_config(dev, hw=96, samples=64, views=4, frames=32,
+                                                  name="configs[3] head: 96x96, K=64 (ResNet-152 384x384), 4 views x 32 frames = 128 pairs")
+        result["extra"]["config5"] = other_config(dev, hw=128, samples=128, views=8, frames=8,
+                                                  name="configs[4] shape: 128x128, K=128 (512x512), 8 views x 8 frames = 64 pairs")
     if rank == 0:
         result["extra"]["mpjpe_delta_mm_vs_reference"] = mpjpe_delta(dev)
     if rank == 0 and not args.no_end_to_end:
