@@ -262,6 +262,13 @@ def main():
             graph.replay()
             return graph_out
 
+    # Set-up, before the W warm-up steps: a few steps that bring the caching allocator to its steady state.  A step allocates
+    # its outputs (0.5 GB each) and the host runs up to RING steps ahead of the device, so the pool needs several blocks of
+    # every size; until it has them a step pays a hipMalloc (a device synchronisation) -- with W = 5 that still happened inside
+    # the timed region (1.33 against 1.15 ms/step on the same box, profiles/r04_bench_modes.txt).
+    for _ in range(2 * RING + 2):
+        layer_step()
+    barrier()
     for _ in range(args.warmup):
         layer_step()
     barrier()

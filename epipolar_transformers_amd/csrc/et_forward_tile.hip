@@ -208,6 +208,7 @@ int et_epipolar_forward_tiled(const EtLayerDesc *desc, const float *xs, const fl
         wp.bias = nullptr;
         wp.x = nullptr;
         wp.err = w.err;
+        wp.tile_ctr = w.ovf_count + 2;
         wp.setprio = (desc->variant & ET_VARIANT_WS_SETPRIO) ? 1 : 0;
 #ifdef ET_WS_PROFILE
         wp.prof = g_ws_prof;
@@ -322,6 +323,7 @@ int et_epipolar_forward_fused(const EtLayerDesc *desc, const float *xs, const fl
     wp.bias = bias;
     wp.x = x;
     wp.err = w.err;
+    wp.tile_ctr = w.ovf_count + 2;
     const int cus = device_cus(dev);
     const unsigned grid = (unsigned)(total < cus ? total : cus);
     const size_t lds_ws = tile_ws_lds_bytes(kTileRowsSmall, desc->H, desc->W);
