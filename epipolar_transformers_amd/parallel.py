@@ -173,7 +173,9 @@ class _ShardedSources(torch.autograd.Function):
     @staticmethod
     def forward(ctx, own_maps, exchange):
         ctx.exchange = exchange
-        return exchange.gather_sources(own_maps.contiguous()).clone()
+        # (a view of the freshly allocated receive buffer when the rank owns one camera, a new tensor otherwise: never an
+        #  alias of the input, so no copy is needed -- round 3 cloned it: one more pass over the source maps per step)
+        return exchange.gather_sources(own_maps.contiguous())
 
     @staticmethod
     def backward(ctx, grad):
