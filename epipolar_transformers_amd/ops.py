@@ -296,9 +296,9 @@ def forward_fused_nhwc(spec: LayerSpec, ref: torch.Tensor, src: torch.Tensor, ca
     assert ref.is_contiguous() and src.is_contiguous() and bias.is_contiguous() and bias.numel() == c
     xs, ys, steps = spec.constants(ref.device)
     x = _empty(None, like=ref)
-    # scratch for the rows of overflow tiles (normally none are written: the pages are never touched); the caching
-    # allocator hands the same block back call after call
-    out = _empty(None, like=ref) if want_out else torch.empty_like(ref)
+    # `out`: requested -> a fresh tensor; otherwise scratch for the rows of overflow tiles only (normally none is written),
+    # one buffer per (device, stream) like the workspace: all use is stream-ordered
+    out = _empty(None, like=ref) if want_out else _workspace(ref.device, ref.numel() * 4, "fwd_out_scratch").view(torch.float32)[:ref.numel()]
     attn = _empty((n, spec.K, h, w), device=ref.device) if want_attn else None
     corr = _empty((n, h, w, 2), device=ref.device) if want_corr else None
     d = spec.desc(n, c)
