@@ -1,4 +1,5 @@
 // libepipolar_amd.so: the MFMA tile formulation of the backward (et_epipolar_backward_tiled).
+#include <algorithm>
 #include "et_common.h"
 
 namespace {
@@ -57,8 +58,6 @@ int et_epipolar_backward_tiled_attn(const EtLayerDesc *desc, const float *xs, co
     tp.hw_words = (HW + 31) / 32;
     tp.rows_cap = tile_rows_cap(desc);
     tp.attn = attn;
-    hipError_t me = hipMemsetAsync(grad_src, 0, (size_t)desc->N * HW * desc->C * sizeof(float), st);
-    if (me != hipSuccess) return fail("hipMemsetAsync(grad_src): %s", hipGetErrorString(me));
     int n2 = 64;
     while (n2 < HW) n2 <<= 1;
     const size_t lds_sort = (size_t)n2 * sizeof(unsigned long long);
@@ -70,8 +69,12 @@ int et_epipolar_backward_tiled_attn(const EtLayerDesc *desc, const float *xs, co
     int *perm = w.perm;
     tp.perm = perm;
     tp.scales = w.scales;
-    hipLaunchKernelGGL(tile_order_kernel, dim3(desc->N), dim3(1024), lds_sort, st, *desc, xs, ys, cam, n2,
-                       tp.tiles_per_pair * kTilePix, perm, (int *)nullptr, feat_ref, feat_src, w.scales, (float4 *)nullptr, (float4 *)nullptr);
+    // grad_src is cleared by extra blocks of the ordering kernel (the tile kernel adds into it): >= 8 float4 stores per thread
+    const size_t clear_vec4 = (size_t)desc->N * HW * (desc->C / 4);     // (C == 256)
+    const unsigned clear_blocks = (unsigned)std::min<size_t>(2048, (clear_vec4 + 8 * 1024 - 1) / (8 * 1024));
+    hipLaunchKernelGGL(tile_order_kernel, dim3(desc->N + clear_blocks), dim3(1024), lds_sort, st, *desc, xs, ys, cam, n2,
+                       tp.tiles_per_pair * kTilePix, perm, (int *)nullptr, feat_ref, feat_src, w.scales, (float4 *)nullptr,
+                       (float4 *)nullptr, reinterpret_cast<float4 *>(grad_src), clear_vec4);
     if (int e = check_launch("et_epipolar_backward_tiled(order)")) return e;
     const int kpl = (desc->K + 63) / 64;
     // 64 x 64 maps, K <= 64: the merged form (two 192-column arrays, one round of atomics per tile) unless the caller
