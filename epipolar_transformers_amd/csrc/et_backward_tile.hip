@@ -58,24 +58,17 @@ int et_epipolar_backward_tiled_attn(const EtLayerDesc *desc, const float *xs, co
     tp.hw_words = (HW + 31) / 32;
     tp.rows_cap = tile_rows_cap(desc);
     tp.attn = attn;
-    int n2 = 64;
-    while (n2 < HW) n2 <<= 1;
-    const size_t lds_sort = (size_t)n2 * sizeof(unsigned long long);
-    const int dev = current_device();
-    ET_GRANT_LDS(tile_order_kernel, lds_sort, dev);
     // (with the per-pair scale estimates of the source maps: the merged kernels run their row-type GEMMs as split-fp16
-    //  products; the workspace has the forward's layout)
-    const TileWorkspace w = carve_tile_workspace(workspace, (size_t)total, (size_t)desc->N);
-    int *perm = w.perm;
-    tp.perm = perm;
+    //  products; the workspace has the forward's layout.  grad_src is cleared by extra blocks of the ordering kernel: the
+    //  tile kernel adds into it)
+    const TileWorkspace w = carve_tile_workspace(workspace, (size_t)total, (size_t)desc->N, (size_t)HW);
+    tp.perm = w.perm;
     tp.scales = w.scales;
-    // grad_src is cleared by extra blocks of the ordering kernel (the tile kernel adds into it): >= 8 float4 stores per thread
     const size_t clear_vec4 = (size_t)desc->N * HW * (desc->C / 4);     // (C == 256)
-    const unsigned clear_blocks = (unsigned)std::min<size_t>(2048, (clear_vec4 + 8 * 1024 - 1) / (8 * 1024));
-    hipLaunchKernelGGL(tile_order_kernel, dim3(desc->N + clear_blocks), dim3(1024), lds_sort, st, *desc, xs, ys, cam, n2,
-                       tp.tiles_per_pair * kTilePix, perm, (int *)nullptr, feat_ref, feat_src, w.scales, (float4 *)nullptr,
-                       (float4 *)nullptr, reinterpret_cast<float4 *>(grad_src), clear_vec4);
-    if (int e = check_launch("et_epipolar_backward_tiled(order)")) return e;
+    if (int e = launch_tile_order(desc, xs, ys, cam, feat_ref, feat_src, w, tp.tiles_per_pair, false, w.scales, false,
+                                  reinterpret_cast<float4 *>(grad_src), clear_vec4, st, "et_epipolar_backward_tiled(order)"))
+        return e;
+    const int dev = current_device();
     const int kpl = (desc->K + 63) / 64;
     // 64 x 64 maps, K <= 64: the merged form (two 192-column arrays, one round of atomics per tile) unless the caller
     // asks for the one-array kernel (ET_VARIANT_TILE_CLASSIC)

@@ -74,7 +74,7 @@ size_t et_epipolar_forward_workspace_bytes(const EtLayerDesc *desc)
 {
     if (validate(desc) || !tile_eligible(desc)) return 0;
     const size_t tiles = (size_t)desc->N * (((size_t)desc->H * desc->W + kTilePix - 1) / kTilePix);
-    size_t words = tile_workspace_words(tiles, (size_t)desc->N);
+    size_t words = tile_workspace_words(tiles, (size_t)desc->N, (size_t)desc->H * desc->W);
     if (tile_ws2_eligible(desc)) words += tile_workspace_plane_words((size_t)desc->N, (size_t)desc->H * desc->W);
     return words * sizeof(int) + 256u;
 }
@@ -131,20 +131,15 @@ int et_epipolar_forward_tiled(const EtLayerDesc *desc, const float *xs, const fl
     tp.tile_list = w.ovf_list;
     tp.tile_count = w.ovf_count;
     // 1. order every pair's reference pixels by their epipolar line (also clears the overflow counter)
-    int n2 = 64;
-    while (n2 < HW) n2 <<= 1;
-    const size_t lds_sort = (size_t)n2 * sizeof(unsigned long long);
     const int dev = current_device();
-    ET_GRANT_LDS(tile_order_kernel, lds_sort, dev);
     // (per-pair scale estimates of the source maps: for the split-fp16 GEMMs of the first-generation persistent kernel and
     //  of the one-block-per-tile kernel; ET_VARIANT_TILE_EXACT keeps the latter in exact fp32)
-    float *scales = w.scales;
     // soft-max off: exact fp32 throughout, as the header promises (the first GEMM feeds the `== 0 -> -1e10` mask and the
     // "attention" sim / K is unbounded: no fp16 form of the B rows)
     tp.scales = ((desc->variant & ET_VARIANT_TILE_EXACT) || !desc->softmax_enabled) ? nullptr : w.scales;
-    hipLaunchKernelGGL(tile_order_kernel, dim3(desc->N), dim3(1024), lds_sort, st, *desc, xs, ys, cam, n2,
-                       tp.tiles_per_pair * kTilePix, w.perm, w.ovf_count, feat_ref, feat_src, scales, w.segs, w.band);
-    if (int e = check_launch("et_epipolar_forward_tiled(order)")) return e;
+    if (int e = launch_tile_order(desc, xs, ys, cam, feat_ref, feat_src, w, tp.tiles_per_pair, true, w.scales, true, nullptr, 0, st,
+                                  "et_epipolar_forward_tiled(order)"))
+        return e;
     const int kpl = (desc->K + 63) / 64;
     const int rows = tile_rows(desc);
     const size_t lds = (size_t)(fwd_tile_array_floats(rows) + rows + kTilePix + 48 + kTilePix * 4) * 4 +
@@ -296,14 +291,10 @@ int et_epipolar_forward_fused(const EtLayerDesc *desc, const float *xs, const fl
     tp.tile_list = w.ovf_list;
     tp.tile_count = w.ovf_count;
     tp.scales = (desc->variant & ET_VARIANT_TILE_EXACT) ? nullptr : w.scales;
-    int n2 = 64;
-    while (n2 < HW) n2 <<= 1;
-    const size_t lds_sort = (size_t)n2 * sizeof(unsigned long long);
     const int dev = current_device();
-    ET_GRANT_LDS(tile_order_kernel, lds_sort, dev);
-    hipLaunchKernelGGL(tile_order_kernel, dim3(desc->N), dim3(1024), lds_sort, st, *desc, xs, ys, cam, n2,
-                       tp.tiles_per_pair * kTilePix, w.perm, w.ovf_count, feat_ref, feat_src, w.scales, w.segs, w.band);
-    if (int e = check_launch("et_epipolar_forward_fused(order)")) return e;
+    if (int e = launch_tile_order(desc, xs, ys, cam, feat_ref, feat_src, w, tp.tiles_per_pair, true, w.scales, true, nullptr, 0, st,
+                                  "et_epipolar_forward_fused(order)"))
+        return e;
     TileWsParams wp;
     wp.f = p;
     wp.f.out = want_out ? out_scratch : nullptr;      // (the persistent kernel writes `out` on request only)

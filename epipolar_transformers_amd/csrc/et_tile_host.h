@@ -1,5 +1,6 @@
 // Host-side helpers shared by the two tile translation units (et_forward_tile.hip, et_backward_tile.hip).
 #pragma once
+#include <algorithm>
 namespace {
 // The MFMA tile path applies to the 256-channel head when one reference pixel alone can never
 // overflow the tile's row array: a pixel's K samples touch at most 4K source pixels, and a line
@@ -49,23 +50,26 @@ bool tile_ws2_eligible(const EtLayerDesc *d)
 //   header (64 words): [0] overflow count, [1] sticky error word -- at the front, so that their offsets do not depend on
 //   the shape of the call (a workspace is reused across shapes) |
 //   perm[tiles * 32] | overflow list[tiles] | stats[tiles] | scales[4 * N] (float) |
-//   segments[tiles * 32] (float4, 16-byte aligned) | band[tiles] (float4: the tile's base line, warp-specialised kernel) |
+//   segments[tiles * 32] (float4, 16-byte aligned; in tile order.  Until tile_order_kernel writes them the region of a pair
+//   holds the pair's sort keys: 8 bytes per pixel, tile_keys_kernel) |
+//   band[tiles] (float4: the tile's base line, warp-specialised kernel) | segments by pixel[N * HW] (float4) |
 //   -- warp-specialised kernel, second generation only: --
 //   rowinv[N * HW] (float) | planes[N * HW * 256] (dwords, 256-byte aligned)
 struct TileWorkspace {
     int *perm, *ovf_count, *err, *ovf_list, *stats;
     float *scales;
-    float4 *segs, *band;
+    float4 *segs, *band, *segs_pix;
     float *rowinv;
     unsigned *planes;
 };
 constexpr size_t kTileWorkspaceHeaderWords = 64;
-size_t tile_workspace_words(size_t tiles, size_t pairs)
+size_t tile_workspace_words(size_t tiles, size_t pairs, size_t hw)
 {
-    return kTileWorkspaceHeaderWords + tiles * kTilePix + 2 * tiles + 4 * pairs + 4 + 4 * tiles * kTilePix + 4 * tiles;
+    return kTileWorkspaceHeaderWords + tiles * kTilePix + 2 * tiles + 4 * pairs + 4 + 4 * tiles * kTilePix + 4 * tiles +
+           4 * pairs * hw;
 }
 size_t tile_workspace_plane_words(size_t pairs, size_t hw) { return pairs * hw + 64 + pairs * hw * 256; }
-TileWorkspace carve_tile_workspace(void *workspace, size_t tiles, size_t pairs, size_t hw = 0)
+TileWorkspace carve_tile_workspace(void *workspace, size_t tiles, size_t pairs, size_t hw)
 {
     TileWorkspace w;
     w.ovf_count = reinterpret_cast<int *>((reinterpret_cast<uintptr_t>(workspace) + 255) & ~(uintptr_t)255);
@@ -76,8 +80,35 @@ TileWorkspace carve_tile_workspace(void *workspace, size_t tiles, size_t pairs, 
     w.scales = reinterpret_cast<float *>(w.stats + tiles);
     w.segs = reinterpret_cast<float4 *>((reinterpret_cast<uintptr_t>(w.scales + 4 * pairs) + 15) & ~(uintptr_t)15);
     w.band = w.segs + tiles * kTilePix;
-    w.rowinv = reinterpret_cast<float *>(w.band + tiles);
+    w.segs_pix = w.band + tiles;
+    w.rowinv = reinterpret_cast<float *>(w.segs_pix + pairs * hw);
     w.planes = reinterpret_cast<unsigned *>((reinterpret_cast<uintptr_t>(w.rowinv + pairs * hw) + 255) & ~(uintptr_t)255);
     return w;
+}
+
+// The ordering of a tile call: tile_keys_kernel (segment and sort key of every reference pixel, whole device; clears the
+// header words when `header`), then tile_order_kernel (one block per pair: sort -> perm, the segments in tile order and the
+// tiles' base lines when `ws_tables`, the scale estimates when `scales`; `clear`: extra blocks that zero a buffer beside the
+// sort -- the backward's grad_src).
+int launch_tile_order(const EtLayerDesc *desc, const float *xs, const float *ys, const float *cam, const float *feat_ref,
+                      const float *feat_src, const TileWorkspace &w, int tiles_per_pair, bool header, float *scales,
+                      bool ws_tables, float4 *clear, size_t clear_vec4, hipStream_t st, const char *who)
+{
+    const int HW = desc->H * desc->W;
+    const int perm_stride = tiles_per_pair * kTilePix;
+    int n2 = 64;
+    while (n2 < HW) n2 <<= 1;
+    const size_t lds_sort = tile_order_lds_bytes(n2);
+    const int dev = current_device();
+    ET_GRANT_LDS(tile_order_kernel, lds_sort, dev);
+    unsigned long long *keys = reinterpret_cast<unsigned long long *>(w.segs);
+    hipLaunchKernelGGL(tile_keys_kernel, dim3((unsigned)((HW + 255) / 256) * desc->N), dim3(256), 0, st, *desc, xs, ys, cam, perm_stride,
+                       keys, w.segs_pix, header ? w.ovf_count : (int *)nullptr);
+    // (the clearing blocks: >= 8 float4 stores per thread)
+    const unsigned clear_blocks = clear ? (unsigned)std::min<size_t>(2048, (clear_vec4 + 8 * 1024 - 1) / (8 * 1024)) : 0u;
+    hipLaunchKernelGGL(tile_order_kernel, dim3(desc->N + clear_blocks), dim3(1024), lds_sort, st, *desc, n2, perm_stride, keys,
+                       w.segs_pix, w.perm, feat_ref, feat_src, scales, ws_tables ? w.segs : (float4 *)nullptr,
+                       ws_tables ? w.band : (float4 *)nullptr, clear, clear_vec4);
+    return check_launch(who);
 }
 }  // namespace

@@ -147,8 +147,8 @@ int et_epipolar_forward(const EtLayerDesc *desc, const float *xs, const float *y
  *               outside the hardware barrier.  The library never synchronises, so the caller reads the word when
  *               it synchronises anyway: ops.check_tile_errors in the Python binding) -- followed by
  *               the per-pair pixel order, the overflow-tile list, per-pair scales, the epipolar
- *               segments and one base line per tile (with ET_VARIANT_WS_V2 also the source planes,
- *               as large as feat_src), and
+ *               segments in tile order, one base line per tile and the segments by pixel (with
+ *               ET_VARIANT_WS_V2 also the source planes, as large as feat_src), and
  *                 - one int32 of statistics per tile ( U | groups << 16 : size of the tile's
  *                   source-row set, number of groups it was split into) starting
  *                   et_epipolar_forward_workspace_stats_offset(desc) bytes in, in tile order

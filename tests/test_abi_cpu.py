@@ -175,12 +175,14 @@ def test_tile_path_eligibility_is_decided_on_the_host(lib):
         return (int(lib.et_epipolar_forward_workspace_bytes(ctypes.byref(d))),
                 int(lib.et_epipolar_backward_tiled_workspace_bytes(ctypes.byref(d))))
 
-    def ws_bytes(tiles, pairs=3, plane_hw=0):
+    def ws_bytes(tiles, pairs=3, plane_hw=0, hw=None):
         # pixel order (32 per tile) | overflow counter + sticky error word (64 words) | overflow list | statistics | scales |
         # segments [| 1 / scale of every source row | alignment | source planes: the warp-specialised kernel (K <= 64, maps
         # up to 64 x 64, soft-max on) keeps the source maps as split-fp16 dwords, as large as feat_src]
         # (header of 64 words first: [0] overflow count, [1] sticky error word; one float4 base line per tile last)
-        words = 64 + tiles * 32 + 2 * tiles + 4 * pairs + 4 + 4 * tiles * 32 + 4 * tiles
+        # ... and the segments by pixel (tile_keys_kernel: the per-pixel half of the ordering), one float4 per pixel
+        hw = (tiles // pairs) * 32 if hw is None else hw
+        words = 64 + tiles * 32 + 2 * tiles + 4 * pairs + 4 + 4 * tiles * 32 + 4 * tiles + 4 * pairs * hw
         if plane_hw:
             words += pairs * plane_hw + 64 + pairs * plane_hw * 256
         return words * 4 + 256
@@ -193,7 +195,7 @@ def test_tile_path_eligibility_is_decided_on_the_host(lib):
     d_ns = ops.LayerSpec(H=64, W=64, K=64, softmax_enabled=False, variant=_lib.ET_VARIANT_WS_V2).desc(3, 256)
     assert int(lib.et_epipolar_forward_workspace_bytes(ctypes.byref(d_ns))) == ws_bytes(3 * 128)   # soft-max off: exact-fp32 tiles
     assert sizes(96, 96, 64, 256)[0] == ws_bytes(3 * 288)           # config 4: 384-row tiles
-    assert sizes(10, 10, 16, 256)[0] == ws_bytes(3 * 4)             # 100 pixels -> 4 padded tiles
+    assert sizes(10, 10, 16, 256)[0] == ws_bytes(3 * 4, hw=100)     # 100 pixels -> 4 padded tiles
     d = ops.LayerSpec(H=64, W=64, K=64).desc(3, 256)
     assert int(lib.et_epipolar_forward_workspace_stats_offset(ctypes.byref(d))) == (64 + 3 * 128 * 32 + 3 * 128) * 4
     # the sticky error word sits in the header: the same offset whatever the shape (a cached workspace is reused across shapes)
