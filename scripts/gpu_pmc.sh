@@ -26,7 +26,7 @@ out = "$OUT/pmc_${TAG}"
 agg = collections.OrderedDict()
 for f in sorted(glob.glob(out + "/g*/**/*counter_collection.csv", recursive=True)):
     for row in csv.DictReader(open(f)):
-        m = re.search(r"(epipolar_\w+|tile_order_kernel)(<[^>]*>)?", row.get("Kernel_Name", ""))
+        m = re.search(r"(epipolar_\w+|tile_\w+_kernel)(<[^>]*>)?", row.get("Kernel_Name", ""))
         if not m:
             continue
         k = (m.group(0), row["Counter_Name"])          # per kernel (template arguments included)

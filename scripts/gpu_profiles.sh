@@ -6,6 +6,9 @@ cd "$ROOT"
 OUT="$ROOT/gpurun_out"; mkdir -p "$OUT"
 TAG=${1:-r04}
 export HSA_ENABLE_IPC_MODE_LEGACY=0
+# ONLY="bench stats pmcbwd" gpu_profiles.sh TAG   runs those sections only (keys: bench two classic perpixel config4 config5
+#   summary stats epilogue pmcfwd pmcfused roles e2e pmcbwd general micro)
+want() { [ -z "$ONLY" ] || [[ " $ONLY " == *" $1 "* ]]; }
 stats() {  # stats NAME -- bench args...   : rocprofv3 --kernel-trace --stats of a bench run, keep the kernel_stats csv
   local name=$1; shift
   (cd /tmp && export TMPDIR=/tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_${TAG}_$name" -o trace -- \
@@ -14,13 +17,13 @@ stats() {  # stats NAME -- bench args...   : rocprofv3 --kernel-trace --stats of
   [ -n "$f" ] && cp "$f" "$OUT/${TAG}_${name}_kernel_stats.csv" && head -6 "$f"
   rm -rf "$OUT/prof_${TAG}_$name"
 }
-echo "== bench (configs[1])"; timeout 900 python bench.py --steps 30 --warmup 5 > "$OUT/${TAG}_bench.json" 2> "$OUT/${TAG}_bench.err"; tail -c 600 "$OUT/${TAG}_bench.json"; echo
-echo "== bench, the step as two kernels (sample+attention, then residual GEMM: rounds 1-3)"; timeout 600 python bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-end-to-end --no-other-configs --two-kernels > "$OUT/${TAG}_bench_two_kernels.json" 2>> "$OUT/${TAG}_bench.err"
-echo "== bench classic (one-block-per-tile kernel, split-fp16 GEMMs)"; timeout 600 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-end-to-end --variant 65536 > "$OUT/${TAG}_bench_variant65536_classic.json" 2>> "$OUT/${TAG}_bench.err"
-echo "== bench per-pixel"; timeout 600 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-end-to-end --variant 16384 > "$OUT/${TAG}_bench_variant16384_perpixel.json" 2>> "$OUT/${TAG}_bench.err"
-echo "== bench config4 head (96x96, K=64, 128 pairs)"; timeout 600 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-end-to-end --hw 96 > "$OUT/${TAG}_bench_config4.json" 2>> "$OUT/${TAG}_bench.err"
-echo "== bench config5 share (128x128, K=128, 8 views x 8 frames = 64 pairs)"; timeout 600 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-end-to-end --samples 128 --hw 128 --frames 8 --views 8 > "$OUT/${TAG}_bench_config5.json" 2>> "$OUT/${TAG}_bench.err"
-python - <<PY
+want bench && { echo "== bench (configs[1])"; timeout 900 python bench.py --steps 30 --warmup 5 > "$OUT/${TAG}_bench.json" 2> "$OUT/${TAG}_bench.err"; tail -c 600 "$OUT/${TAG}_bench.json"; echo; }
+want two && { echo "== bench, the step as two kernels (sample+attention, then residual GEMM: rounds 1-3)"; timeout 600 python bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-end-to-end --no-other-configs --two-kernels > "$OUT/${TAG}_bench_two_kernels.json" 2>> "$OUT/${TAG}_bench.err"; }
+want classic && { echo "== bench classic (one-block-per-tile kernel, split-fp16 GEMMs)"; timeout 600 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-end-to-end --variant 65536 > "$OUT/${TAG}_bench_variant65536_classic.json" 2>> "$OUT/${TAG}_bench.err"; }
+want perpixel && { echo "== bench per-pixel"; timeout 600 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-end-to-end --variant 16384 > "$OUT/${TAG}_bench_variant16384_perpixel.json" 2>> "$OUT/${TAG}_bench.err"; }
+want config4 && { echo "== bench config4 head (96x96, K=64, 128 pairs)"; timeout 600 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-end-to-end --hw 96 > "$OUT/${TAG}_bench_config4.json" 2>> "$OUT/${TAG}_bench.err"; }
+want config5 && { echo "== bench config5 share (128x128, K=128, 8 views x 8 frames = 64 pairs)"; timeout 600 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-end-to-end --samples 128 --hw 128 --frames 8 --views 8 > "$OUT/${TAG}_bench_config5.json" 2>> "$OUT/${TAG}_bench.err"; }
+want summary && python - <<PY
 import json
 for n in ("bench", "bench_two_kernels", "bench_variant65536_classic", "bench_variant16384_perpixel", "bench_config4", "bench_config5"):
     try:
@@ -29,10 +32,13 @@ for n in ("bench", "bench_two_kernels", "bench_variant65536_classic", "bench_var
     except Exception as e:
         print(n, "failed", e)
 PY
+want stats && {
 echo "== rocprof kernel stats"
 stats bench --steps 10 --warmup 3 --no-cpu-baseline
 stats config4 --steps 5 --warmup 2 --no-cpu-baseline --hw 96
 stats config5 --steps 5 --warmup 2 --no-cpu-baseline --samples 128 --hw 128 --frames 8 --views 8
+}
+want epilogue && {
 echo "== residual epilogue kernel"
 (cd /tmp && export TMPDIR=/tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_${TAG}_epi" -o trace -- python - <<PY > "$OUT/${TAG}_epilogue_rocprof.log" 2>&1
 import sys, torch
@@ -48,13 +54,16 @@ torch.cuda.synchronize()
 PY
 )
 f=$(find "$OUT/prof_${TAG}_epi" -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" "$OUT/${TAG}_epilogue_kernel_stats.csv" && head -4 "$f"; rm -rf "$OUT/prof_${TAG}_epi"
-echo "== PMC forward"; bash scripts/gpu_pmc.sh "${TAG}_fwd_tile" 0 fwd | tail -34
-echo "== PMC one-kernel layer"; bash scripts/gpu_pmc.sh "${TAG}_fwd_fused" 0 fused | tail -34
-echo "== role experiments of the warp-specialised forward"; [ -f epipolar_transformers_amd/lib/libepipolar_amd_prof.so ] && EPIPOLAR_AMD_LIB=$ROOT/epipolar_transformers_amd/lib/libepipolar_amd_prof.so timeout 300 python scripts/ws_experiment.py 2>&1 | grep -v amdgpu.ids | tee "$OUT/${TAG}_ws_role_experiment.txt"
-echo "== end to end at the larger image sizes"; (timeout 400 python scripts/e2e_shapes.py --image 384 --frames 32 --views 4; timeout 400 python scripts/e2e_shapes.py --image 512 --frames 8 --views 8 --samples 128; timeout 400 python scripts/e2e_shapes.py --image 384 --frames 8 --views 4 --body epipolarposeR-152) 2>&1 | grep -v amdgpu.ids | tee "$OUT/${TAG}_e2e_shapes.txt"
-echo "== PMC backward"; bash scripts/gpu_pmc.sh "${TAG}_bwd_tile" 0 bwd | tail -34
-echo "== parameterised + pooled head through the general kernel"; timeout 300 python scripts/general_mode_time.py 2>/dev/null | tail -1 | tee "$OUT/${TAG}_general_mode_time.txt"
+}
+want pmcfwd && { echo "== PMC forward"; bash scripts/gpu_pmc.sh "${TAG}_fwd_tile" 0 fwd | tail -34; }
+want pmcfused && { echo "== PMC one-kernel layer"; bash scripts/gpu_pmc.sh "${TAG}_fwd_fused" 0 fused | tail -34; }
+want roles && { echo "== role experiments of the warp-specialised forward"; [ -f epipolar_transformers_amd/lib/libepipolar_amd_prof.so ] && EPIPOLAR_AMD_LIB=$ROOT/epipolar_transformers_amd/lib/libepipolar_amd_prof.so timeout 300 python scripts/ws_experiment.py 2>&1 | grep -v amdgpu.ids | tee "$OUT/${TAG}_ws_role_experiment.txt"; }
+want e2e && { echo "== end to end at the larger image sizes"; (timeout 400 python scripts/e2e_shapes.py --image 384 --frames 32 --views 4; timeout 400 python scripts/e2e_shapes.py --image 512 --frames 8 --views 8 --samples 128; timeout 400 python scripts/e2e_shapes.py --image 384 --frames 8 --views 4 --body epipolarposeR-152) 2>&1 | grep -v amdgpu.ids | tee "$OUT/${TAG}_e2e_shapes.txt"; }
+want pmcbwd && { echo "== PMC backward"; bash scripts/gpu_pmc.sh "${TAG}_bwd_tile" 0 bwd | tail -34; }
+want general && { echo "== parameterised + pooled head through the general kernel"; timeout 300 python scripts/general_mode_time.py 2>/dev/null | tail -1 | tee "$OUT/${TAG}_general_mode_time.txt"; }
+want micro && {
 echo "== microbenchmarks"
 for m in mfma_valu_overlap mfma_valu_samewave load_patterns mfma_lds_rates; do
   [ -x scripts/micro/$m ] && timeout 120 scripts/micro/$m > "$OUT/${TAG}_micro_$m.txt" 2>&1 && tail -3 "$OUT/${TAG}_micro_$m.txt"
 done
+}
