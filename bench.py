@@ -357,7 +357,8 @@ def main():
     # is carried beside it against the dense fp32 peak (157.3 TFLOP/s, vector = matrix).  Whether the 50 %-of-HBM target is
     # reachable in EXACT fp32 is computed below from the fp32 MFMA flops the tiles of this very batch issue.
     d_ = spec.desc(n_pairs, C)
-    tile_bits = (_lib.ET_VARIANT_TILE_CLASSIC | _lib.ET_VARIANT_WS_V2 | _lib.ET_VARIANT_WS_SETPRIO | _lib.ET_VARIANT_TILE_EXACT)
+    tile_bits = (_lib.ET_VARIANT_TILE_CLASSIC | _lib.ET_VARIANT_WS_V2 | _lib.ET_VARIANT_WS_SETPRIO | _lib.ET_VARIANT_TILE_EXACT |
+                 _lib.ET_VARIANT_WS_BAND)
     tiled = (args.variant & ~tile_bits) == 0 and int(_lib.load().et_epipolar_forward_workspace_bytes(ctypes.byref(d_))) > 0
     split = tiled and not (args.variant & _lib.ET_VARIANT_TILE_EXACT)
     ws = split and not (args.variant & _lib.ET_VARIANT_TILE_CLASSIC) and K <= 64 and H <= 64 and W <= 64
@@ -370,15 +371,15 @@ def main():
     roofline = {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src if traffic else None,
                 "algorithmic_bytes_per_launch": bytes_launch, "kernel_ms": kernel_ms, "kernel_ms_min": k_ms[0],
-                "kernel": ("epipolar_fwd_tile_ws_kernel<256, 8, true>: sampling + attention + the z / BN / residual GEMM (et_epipolar_forward_fused)"
-                           if one_kernel else "epipolar_fwd_tile_ws2_kernel (+ source_planes_kernel)" if ws and (args.variant & _lib.ET_VARIANT_WS_V2)
+                "kernel": ("epipolar_fwd_tile_ws_kernel<%s>: sampling + attention + the z / BN / residual GEMM (et_epipolar_forward_fused)"
+                           % ws_instance(H, W, True) if one_kernel else "epipolar_fwd_tile_ws2_kernel (+ source_planes_kernel)" if ws and (args.variant & _lib.ET_VARIANT_WS_V2)
                            else "epipolar_fwd_tile_ws_kernel" if ws else "epipolar_fwd_tile_kernel" if tiled
-                           else "epipolar_fwd_kernel") + " (+ tile_order_kernel)" * bool(tiled),
+                           else "epipolar_fwd_kernel") + " (+ tile_keys_kernel, tile_order_kernel)" * bool(tiled),
                 "fp32_flops": flop}
     if one_kernel:
         # the sample + attention kernel alone (et_epipolar_forward_tiled: what writes `out`; the kernel rounds 1-3 reported
         # here and the one the 50 %-of-HBM target of BASELINE.json names), same algorithmic bytes
-        roofline["sample_attention_kernel"] = {"kernel": "epipolar_fwd_tile_ws_kernel<256, 8, false> (+ tile_order_kernel)",
+        roofline["sample_attention_kernel"] = {"kernel": "epipolar_fwd_tile_ws_kernel<%s> (+ tile_keys_kernel, tile_order_kernel)" % ws_instance(H, W, False),
                                                "kernel_ms": sa_kernel_ms, "kernel_ms_min": sa_ms[0],
                                                "achieved": bytes_launch / (sa_kernel_ms * 1e-3) / 1e9,
                                                "frac": bytes_launch / (sa_kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
@@ -429,10 +430,10 @@ def main():
                    "variant": args.variant,
                    "launch": "one hipGraph per step (host algebra every step, outside the graph)" if graphed
                              else "kernel by kernel from Python",
-                   "step_kernels": "tile_order_kernel + epipolar_fwd_tile_ws_kernel<256, 8, true> (sampling, attention, z / BN / residual GEMM) "
-                                   "+ two overflow-list kernels (normally empty)" if (packed_w is not None and fuse3 and
+                   "step_kernels": "tile_keys_kernel + tile_order_kernel + epipolar_fwd_tile_ws_kernel<%s> (sampling, attention, z / BN / residual GEMM) "
+                                   "+ two overflow-list kernels (normally empty)" % ws_instance(H, W, True) if (packed_w is not None and fuse3 and
                                                                                       ops.fused_layer_applies(spec, C, n_pairs) and exchange is None)
-                                   else "tile_order_kernel + fused sample+attention kernel + residual GEMM kernel",
+                                   else "tile_keys_kernel + tile_order_kernel + fused sample+attention kernel + residual GEMM kernel",
                    "host_algebra": "per step, at the start of the step" if (args.serial_host or graphed or exchange is not None)
                                    else "per step, computed for step i+1 while the device runs step i"},
         "roofline": roofline,
@@ -466,6 +467,13 @@ def main():
         dist.destroy_process_group()
 
 
+def ws_instance(h, w, fused):
+    """template arguments of the persistent kernel that takes an h x w map (et_tile_host.h: 256-row arrays up to 64 x 64,
+    288-row arrays and a slot table over the tile's band up to 96 x 96)"""
+    fused = fused if isinstance(fused, str) else ("true" if fused else "false")
+    return ("256, 8, %s, false" if max(h, w) <= 64 else "288, 8, %s, true") % fused
+
+
 def other_config(dev, hw, samples, views, frames, name, C=256):
     """The fused forward / backward kernels at another BASELINE head shape (fewer pairs than the headline: same kernels,
     same per-pair work), HIP events around the calls: ms, pair-views/s and the fraction of the HBM roofline."""
@@ -494,15 +502,28 @@ def other_config(dev, hw, samples, views, frames, name, C=256):
     f_ms = timed(lambda: ops.forward_nhwc(spec, ref, src, cam))
     attn = ops.forward_nhwc(spec, ref, src, cam)[1]
     b_ms = timed(lambda: ops.backward_nhwc(spec, ref, src, cam, gout, attn=attn))
+    # the eval-mode layer (x = feat + bias + out . Wf^T): one kernel where the persistent kernel covers the shape (maps up to
+    # 96 x 96, K <= 64), else the sample + attention kernel followed by residual_gemm_kernel
+    packed = ops.residual_gemm_pack(torch.randn(C, C, device=dev, generator=g) * 0.05 + torch.eye(C, device=dev))
+    bias = torch.randn(C, device=dev, generator=g)
+    one_kernel = ops.fused_layer_applies(spec, C, n)
+    if one_kernel:
+        l_ms = timed(lambda: ops.forward_fused_nhwc(spec, ref, src, cam, packed, bias))
+    else:
+        l_ms = timed(lambda: ops.residual_gemm(ops.forward_nhwc(spec, ref, src, cam)[0], packed, bias, ref))
     ops.check_tile_errors()
     fb = algorithmic_bytes_per_pair(C, hw, hw, samples) * n
     bb = (5 * C * hw * hw * 4 + samples * hw * hw * 4) * n      # reads feat_ref, feat_src, grad_out, attn; writes both gradients
     kpl = (samples + 63) // 64
     rows = 256 if hw <= 64 else (512 if 4 * min(samples, hw) > 384 else 384)
+    persistent = samples <= 64 and hw <= 96           # (et_tile_host.h: tile_ws_eligible)
+    ws_name = "epipolar_fwd_tile_ws_kernel<" + ws_instance(hw, hw, "%s") + ">"
     return {"workload": name, "pairs": n, "forward_ms": f_ms, "forward_frac_of_hbm_peak": fb / (f_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
             "forward_pair_views_per_s": n / (f_ms * 1e-3),
-            "forward_kernel": "epipolar_fwd_tile_kernel<%d, %d> (+ tile_order_kernel)" % (kpl, rows) if hw > 64 or samples > 64
-                              else "epipolar_fwd_tile_ws_kernel (+ tile_order_kernel)",
+            "forward_kernel": (ws_name % "false" if persistent else "epipolar_fwd_tile_kernel<%d, %d>" % (kpl, rows)) +
+                              " (+ tile_keys_kernel, tile_order_kernel)",
+            "layer_ms": l_ms, "layer_pair_views_per_s": n / (l_ms * 1e-3),
+            "layer_kernels": (ws_name % "true") if one_kernel else "the forward kernel + residual_gemm_kernel",
             "backward_ms": b_ms, "backward_frac_of_hbm_peak": bb / (b_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
             "algorithmic_bytes_forward": fb, "algorithmic_bytes_backward": bb}
 

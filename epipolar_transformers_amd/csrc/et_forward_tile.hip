@@ -213,15 +213,28 @@ int et_epipolar_forward_tiled(const EtLayerDesc *desc, const float *xs, const fl
 #endif
         const int cus = device_cus(dev);
         const unsigned grid = (unsigned)(total < cus ? total : cus);
-        const size_t lds_ws = tile_ws_lds_bytes(kTileRowsSmall, desc->H, desc->W);
-        ET_SET_LDS((epipolar_fwd_tile_ws_kernel<kTileRowsSmall, 8>), lds_ws);
-        hipLaunchKernelGGL((epipolar_fwd_tile_ws_kernel<kTileRowsSmall, 8>), dim3(grid), dim3((kWsMatrixWaves + 8) * kWave),
-                           lds_ws, st, wp);
+        if (tile_ws_band(desc)) {       // maps above 64 x 64 (up to 96 x 96): 288-row arrays, slot table over the tile's band
+            if (wp.rows_cap > kTileRowsWsLarge) wp.rows_cap = kTileRowsWsLarge;
+            const size_t lds_ws = tile_ws_lds_bytes(kTileRowsWsLarge, desc->H, desc->W, true);
+            ET_SET_LDS((epipolar_fwd_tile_ws_kernel<kTileRowsWsLarge, 8, false, true>), lds_ws);
+            hipLaunchKernelGGL((epipolar_fwd_tile_ws_kernel<kTileRowsWsLarge, 8, false, true>), dim3(grid),
+                               dim3((kWsMatrixWaves + 8) * kWave), lds_ws, st, wp);
+        } else {
+            const size_t lds_ws = tile_ws_lds_bytes(kTileRowsSmall, desc->H, desc->W);
+            ET_SET_LDS((epipolar_fwd_tile_ws_kernel<kTileRowsSmall, 8>), lds_ws);
+            hipLaunchKernelGGL((epipolar_fwd_tile_ws_kernel<kTileRowsSmall, 8>), dim3(grid), dim3((kWsMatrixWaves + 8) * kWave),
+                               lds_ws, st, wp);
+        }
         if (int e = check_launch("et_epipolar_forward_tiled(ws)")) return e;
         // ... 2b'. and the tiles it left over one block per tile
         const unsigned lgrid = (unsigned)(total < 2LL * cus ? total : 2LL * cus);
-        ET_SET_LDS((epipolar_fwd_tile_list_kernel<1, kTileRowsSmall>), lds);
-        hipLaunchKernelGGL((epipolar_fwd_tile_list_kernel<1, kTileRowsSmall>), dim3(lgrid), dim3(256), lds, st, tp);
+        if (rows == kTileRowsLarge) {
+            ET_SET_LDS((epipolar_fwd_tile_list_kernel<1, kTileRowsLarge>), lds);
+            hipLaunchKernelGGL((epipolar_fwd_tile_list_kernel<1, kTileRowsLarge>), dim3(lgrid), dim3(256), lds, st, tp);
+        } else {
+            ET_SET_LDS((epipolar_fwd_tile_list_kernel<1, kTileRowsSmall>), lds);
+            hipLaunchKernelGGL((epipolar_fwd_tile_list_kernel<1, kTileRowsSmall>), dim3(lgrid), dim3(256), lds, st, tp);
+        }
         return check_launch("et_epipolar_forward_tiled(list)");
     }
     // 2. one block per tile
@@ -261,7 +274,7 @@ int et_epipolar_forward_fused(const EtLayerDesc *desc, const float *xs, const fl
         return fail("et_epipolar_forward_fused: NULL pointer");
     if (reinterpret_cast<uintptr_t>(packed_w) & 15) return fail("et_epipolar_forward_fused: packed weight must be 16-byte aligned");
     if (!tile_eligible(desc) || !tile_ws_eligible(desc) || tile_ws2_eligible(desc))
-        return fail("et_epipolar_forward_fused: needs the warp-specialised tile kernel (C == 256, maps up to 64 x 64, K <= 64, "
+        return fail("et_epipolar_forward_fused: needs the warp-specialised tile kernel (C == 256, maps up to 96 x 96, K <= 64, "
                     "soft-max on; got C=%d H=%d W=%d K=%d variant=%d): use et_epipolar_forward_tiled + et_residual_gemm",
                     desc->C, desc->H, desc->W, desc->K, desc->variant);
     const size_t need = et_epipolar_forward_workspace_bytes(desc);
@@ -317,10 +330,18 @@ int et_epipolar_forward_fused(const EtLayerDesc *desc, const float *xs, const fl
     wp.tile_ctr = w.ovf_count + 2;
     const int cus = device_cus(dev);
     const unsigned grid = (unsigned)(total < cus ? total : cus);
-    const size_t lds_ws = tile_ws_lds_bytes(kTileRowsSmall, desc->H, desc->W);
-    ET_GRANT_LDS((epipolar_fwd_tile_ws_kernel<kTileRowsSmall, 8, true>), lds_ws, dev);
-    hipLaunchKernelGGL((epipolar_fwd_tile_ws_kernel<kTileRowsSmall, 8, true>), dim3(grid), dim3((kWsMatrixWaves + 8) * kWave),
-                       lds_ws, st, wp);
+    if (tile_ws_band(desc)) {
+        if (wp.rows_cap > kTileRowsWsLarge) wp.rows_cap = kTileRowsWsLarge;
+        const size_t lds_ws = tile_ws_lds_bytes(kTileRowsWsLarge, desc->H, desc->W, true);
+        ET_GRANT_LDS((epipolar_fwd_tile_ws_kernel<kTileRowsWsLarge, 8, true, true>), lds_ws, dev);
+        hipLaunchKernelGGL((epipolar_fwd_tile_ws_kernel<kTileRowsWsLarge, 8, true, true>), dim3(grid),
+                           dim3((kWsMatrixWaves + 8) * kWave), lds_ws, st, wp);
+    } else {
+        const size_t lds_ws = tile_ws_lds_bytes(kTileRowsSmall, desc->H, desc->W);
+        ET_GRANT_LDS((epipolar_fwd_tile_ws_kernel<kTileRowsSmall, 8, true>), lds_ws, dev);
+        hipLaunchKernelGGL((epipolar_fwd_tile_ws_kernel<kTileRowsSmall, 8, true>), dim3(grid), dim3((kWsMatrixWaves + 8) * kWave),
+                           lds_ws, st, wp);
+    }
     if (int e = check_launch("et_epipolar_forward_fused(ws)")) return e;
     // the tiles it left over: `out` rows one block per tile, then their x rows
     const int kpl = 1;
@@ -328,8 +349,13 @@ int et_epipolar_forward_fused(const EtLayerDesc *desc, const float *xs, const fl
     const size_t lds = (size_t)(fwd_tile_array_floats(rows) + rows + kTilePix + 48 + kTilePix * 4) * 4 +
                        (size_t)tp.hw_words * 8 + (kpl == 1 ? (size_t)kTilePix * kWave * 8 : 0);
     const unsigned lgrid = (unsigned)(total < 2LL * cus ? total : 2LL * cus);
-    ET_GRANT_LDS((epipolar_fwd_tile_list_kernel<1, kTileRowsSmall>), lds, dev);
-    hipLaunchKernelGGL((epipolar_fwd_tile_list_kernel<1, kTileRowsSmall>), dim3(lgrid), dim3(256), lds, st, tp);
+    if (rows == kTileRowsLarge) {
+        ET_GRANT_LDS((epipolar_fwd_tile_list_kernel<1, kTileRowsLarge>), lds, dev);
+        hipLaunchKernelGGL((epipolar_fwd_tile_list_kernel<1, kTileRowsLarge>), dim3(lgrid), dim3(256), lds, st, tp);
+    } else {
+        ET_GRANT_LDS((epipolar_fwd_tile_list_kernel<1, kTileRowsSmall>), lds, dev);
+        hipLaunchKernelGGL((epipolar_fwd_tile_list_kernel<1, kTileRowsSmall>), dim3(lgrid), dim3(256), lds, st, tp);
+    }
     if (int e = check_launch("et_epipolar_forward_fused(list)")) return e;
     hipLaunchKernelGGL(residual_rows_list_kernel, dim3((unsigned)(total < cus ? total : cus)), dim3(256), 0, st, w.perm,
                        w.ovf_list, w.ovf_count, tp.tiles_per_pair, HW, out_scratch, feat_ref,

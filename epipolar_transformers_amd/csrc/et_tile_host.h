@@ -33,17 +33,27 @@ bool tile_eligible(const EtLayerDesc *d)
 // GEMM holds the B rows (attention x bilinear weights, <= 1 with the soft-max) in fp16 pairs; with
 // EPIPOLAR.SOFTMAX_ENABLED False the "attention" is sim / K -- unbounded, -1e10 / K on masked samples -- and the call
 // takes the exact-fp32 one-block-per-tile kernel.
+// Two instances: 256-row arrays and a whole-map slot table for maps up to 64 x 64; 288-row arrays and a slot table over the
+// tile's band for maps up to 96 x 96 (every tile of a 96 x 96 map has at most 280 rows; ET_VARIANT_WS_BAND: also for smaller
+// maps, where it must return what the first returns -- the test of the band-table code).
+bool tile_ws_band(const EtLayerDesc *d)
+{
+    const int longest = d->W > d->H ? d->W : d->H;
+    if ((d->variant & ET_VARIANT_TILE_CLASSIC) || !d->softmax_enabled || d->K > 64 || d->W < 2 || longest > kWsMaxSideBand)
+        return false;
+    return tile_rows(d) == kTileRowsLarge || ((d->variant & ET_VARIANT_WS_BAND) && tile_rows(d) == kTileRowsSmall);
+}
 bool tile_ws_eligible(const EtLayerDesc *d)
 {
-    return !(d->variant & ET_VARIANT_TILE_CLASSIC) && d->softmax_enabled && d->K <= 64 && d->W >= 2 &&
-           tile_rows(d) == kTileRowsSmall;
+    return (!(d->variant & ET_VARIANT_TILE_CLASSIC) && d->softmax_enabled && d->K <= 64 && d->W >= 2 &&
+            tile_rows(d) == kTileRowsSmall) || tile_ws_band(d);
 }
 // second generation (pre-split source planes with exact per-row scales, row masks: kernels_forward_tile_ws2.inc), on
 // request (ET_VARIANT_WS_V2): measured slower than the first on MI355X (profiles/r03_ws2_*), kept as the variant whose
 // arithmetic needs no scale estimate at all
 bool tile_ws2_eligible(const EtLayerDesc *d)
 {
-    return tile_ws_eligible(d) && (d->variant & ET_VARIANT_WS_V2) && d->W <= 64 && d->H <= 64;
+    return tile_ws_eligible(d) && !tile_ws_band(d) && (d->variant & ET_VARIANT_WS_V2) && d->W <= 64 && d->H <= 64;
 }
 
 // Workspace of the tile forward (all int32, base aligned up to 256 bytes):

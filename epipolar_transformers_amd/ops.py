@@ -217,7 +217,7 @@ class GeneralAttend(torch.autograd.Function):
 
 
 _TILE_BITS = (_lib.ET_VARIANT_TILE_SPLIT | _lib.ET_VARIANT_TILE_CLASSIC | _lib.ET_VARIANT_WS_V2 |
-              _lib.ET_VARIANT_WS_SETPRIO | _lib.ET_VARIANT_TILE_EXACT)      # variant bits that tune the tile path instead of leaving it
+              _lib.ET_VARIANT_WS_SETPRIO | _lib.ET_VARIANT_TILE_EXACT | _lib.ET_VARIANT_WS_BAND)   # bits that tune the tile path instead of leaving it
 
 
 def forward_nhwc(spec: LayerSpec, ref: torch.Tensor, src: torch.Tensor, cam: torch.Tensor,
@@ -271,9 +271,9 @@ def forward_nhwc(spec: LayerSpec, ref: torch.Tensor, src: torch.Tensor, cam: tor
 
 def fused_layer_applies(spec: LayerSpec, c: int, n: int = 1) -> bool:
     """True when et_epipolar_forward_fused covers this shape (the warp-specialised tile kernel: C == 256, maps up to
-    64 x 64, K <= 64, soft-max on, no variant bit that leaves that kernel)."""
-    allowed = _lib.ET_VARIANT_TILE_SPLIT | _lib.ET_VARIANT_WS_SETPRIO
-    if not (c == 256 and 2 <= spec.W <= 64 and spec.H <= 64 and spec.K <= 64 and spec.softmax_enabled and
+    96 x 96, K <= 64, soft-max on, no variant bit that leaves that kernel)."""
+    allowed = _lib.ET_VARIANT_TILE_SPLIT | _lib.ET_VARIANT_WS_SETPRIO | _lib.ET_VARIANT_WS_BAND
+    if not (c == 256 and 2 <= spec.W <= 96 and spec.H <= 96 and spec.K <= 64 and spec.softmax_enabled and
             (spec.variant & ~allowed) == 0):
         return False
     d = spec.desc(n, c)

@@ -81,6 +81,7 @@ typedef struct EtLayerDesc {
 #define ET_VARIANT_TILE_CLASSIC 65536 /* et_epipolar_forward_tiled: the one-block-per-tile kernel (split-fp16 GEMMs, exact-fp32 redo of overflowing tiles) instead of the warp-specialised persistent one */
 #define ET_VARIANT_WS_V2 131072   /* et_epipolar_forward_tiled: the second-generation warp-specialised kernel (source maps pre-split into fp16 planes under exact per-row scales; kernels_forward_tile_ws2.inc) instead of the first */
 #define ET_VARIANT_WS_SETPRIO 262144 /* warp-specialised kernel (first generation), tuning: s_setprio 1 on the matrix waves */
+#define ET_VARIANT_WS_BAND 1048576 /* et_epipolar_forward_tiled / _fused, testing: the persistent kernel's instance for maps above 64 x 64 (288-row arrays, slot table over the tile's band) also for smaller maps */
 #define ET_VARIANT_TILE_EXACT 524288 /* et_epipolar_forward_tiled, one-block-per-tile kernel: both GEMMs in exact fp32 (v_mfma_f32_32x32x2_f32) instead of split-fp16 products */
 #define ET_VARIANT_BASELINE 256    /* batches of 8, compiler-chosen registers, pixels 4w..4w+3 per wave   */
 /* Bits 64 and 128 are reserved: in development builds of the library (-DET_DEV_ABLATE) they switch the per-pixel

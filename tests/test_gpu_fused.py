@@ -46,8 +46,11 @@ def _bound(out, wf, want):
 
 
 @pytest.mark.parametrize("n,h,k,variant,outlier", [(8, 64, 64, 0, False), (5, 48, 33, 0, False), (4, 16, 16, 0, False),
-                                                   (4, 16, 16, 32768, False), (4, 64, 64, 0, True), (3, 33, 20, 0, False)],
-                         ids=["64x64-K64", "48x48-K33", "16x16-K16", "16x16-K16-overflow-tiles", "64x64-K64-fp16-guard", "33x33-K20"])
+                                                   (4, 16, 16, 32768, False), (4, 64, 64, 0, True), (3, 33, 20, 0, False),
+                                                   (3, 96, 64, 0, False), (2, 96, 16, 32768, False), (2, 80, 40, 0, True),
+                                                   (4, 48, 33, 1048576, False)],
+                         ids=["64x64-K64", "48x48-K33", "16x16-K16", "16x16-K16-overflow-tiles", "64x64-K64-fp16-guard", "33x33-K20",
+                              "96x96-K64", "96x96-K16-overflow-tiles", "80x80-K40-fp16-guard", "48x48-K33-band-instance"])
 def test_fused_layer_vs_two_kernels_and_float64(env, n, h, k, variant, outlier):
     _lib, camera, ops = env
     P1, P2, f1, f2, wf, bias = _inputs(n, h, seed=50 + h + k, outlier=outlier)
@@ -75,7 +78,7 @@ def test_fused_layer_vs_two_kernels_and_float64(env, n, h, k, variant, outlier):
     # without `out` (the product path): same x, and the scratch is only touched for overflow tiles
     x3, attn3, corr3 = ops.forward_fused_nhwc(spec, ref, src, cam, packed, bias_d)
     assert torch.equal(x3, x1) and torch.equal(attn3, attn1) and torch.equal(corr3, corr1)
-    if variant or outlier:
+    if (variant & 32768) or outlier:
         base = (-ws.data_ptr()) % 256
         assert int(ws[base:base + 4].view(torch.int32).item()) > 0, "the case was meant to put tiles on the overflow list"
 
@@ -140,13 +143,15 @@ def test_fused_layer_is_what_the_module_runs_in_eval(env):
 
 def test_fused_entry_refuses_shapes_of_the_other_kernels(env):
     _lib, camera, ops = env
-    assert not ops.fused_layer_applies(ops.LayerSpec(H=96, W=96, K=64), C, 2)
+    assert ops.fused_layer_applies(ops.LayerSpec(H=96, W=96, K=64), C, 2)          # (since the band-table instance: up to 96 x 96)
+    assert not ops.fused_layer_applies(ops.LayerSpec(H=128, W=128, K=64), C, 2)
+    assert not ops.fused_layer_applies(ops.LayerSpec(H=96, W=97, K=64), C, 2)
     assert not ops.fused_layer_applies(ops.LayerSpec(H=64, W=64, K=128), C, 2)
     assert not ops.fused_layer_applies(ops.LayerSpec(H=64, W=64, K=64, softmax_enabled=False), C, 2)
     assert not ops.fused_layer_applies(ops.LayerSpec(H=64, W=64, K=64), 128, 2)
     assert not ops.fused_layer_applies(ops.LayerSpec(H=64, W=64, K=64, variant=_lib.ET_VARIANT_TILE_CLASSIC), C, 2)
-    spec = ops.LayerSpec(H=96, W=96, K=64)
-    t = torch.zeros(1, 96, 96, C, device="cuda")
+    spec = ops.LayerSpec(H=128, W=128, K=64)
+    t = torch.zeros(1, 128, 128, C, device="cuda")
     with pytest.raises(_lib.EpipolarAmdError):
         ops.forward_fused_nhwc(spec, t, t, torch.zeros(1, 27, device="cuda"), ops.residual_gemm_pack(torch.eye(C, device="cuda")),
                                torch.zeros(C, device="cuda"))
