@@ -431,7 +431,7 @@ class Epipolar(nn.Module):
 
     def forward_fused(self, feat1, feat2, P1, P2, camera=None, other_camera=None):
         """forward + `ret + feat` (resnet.py:388).  In eval mode the whole epilogue is ONE GEMM, x = feat + bf + out @ Wf^T:
-        for the 256-channel head on maps up to 64 x 64 (K <= 64) a third GEMM INSIDE the persistent forward kernel
+        for the 256-channel head on maps up to 96 x 96 (K <= 64) a third GEMM INSIDE the persistent forward kernel
         (`ops.forward_fused_nhwc`: `out` never goes through HBM), for the other 256-channel shapes `ops.residual_gemm` behind
         the forward; other widths: the fused kernel emits feat + bf and a library GEMM accumulates into it.
         Returns (x, corr_pos, depth, None)."""

@@ -122,16 +122,17 @@ int et_epipolar_forward(const EtLayerDesc *desc, const float *xs, const float *y
 /* The same operator in its MFMA tile formulation (C == 256 head): reference pixels are ordered by
  * their epipolar line, 32 neighbouring lines form a tile, and the channel-long work of the tile runs
  * as two GEMMs on the matrix cores against the union of the source rows the tile touches (each source
- * row is fetched per tile, not per pixel).  For K <= 64 on maps up to 64 x 64 with the soft-max on
- * (every headline config) the call is one persistent block per compute unit whose waves are
+ * row is fetched per tile, not per pixel).  For K <= 64 on maps up to 96 x 96 with the soft-max on
+ * (BASELINE configs[0..3]) the call is one persistent block per compute unit whose waves are
  * specialised: matrix waves run the two GEMMs of consecutive tiles back to back as split-fp16 MFMAs
  * with fp32 accumulation (~22 significant bits per product; the fp32 operands are scaled by powers of
  * two, split into fp16 hi + lo at the point of use and every converted value is range-checked), vector
- * waves do the geometry / row-set / soft-max work of the neighbouring tiles meanwhile.
+ * waves do the geometry / row-set / soft-max work of the neighbouring tiles meanwhile (two instances:
+ * 256-row arrays up to 64 x 64 maps; 288-row arrays and a slot table over the tile's band above).
  * ET_VARIANT_WS_V2 selects a second form of that kernel that first rewrites the source maps as
  * split-fp16 planes (one dword ( hi | lo << 16 ) per value, one exact power-of-two scale per pixel row;
  * kept in the workspace) -- measured slower on MI355X, not the default.  Other shapes (maps above
- * 64 x 64, K > 64) run one block per tile with the same split-fp16 GEMMs.  A tile with a value beyond
+ * 96 x 96, K > 64) run one block per tile with the same split-fp16 GEMMs.  A tile with a value beyond
  * fp16's range is redone in exact fp32, and so is every call with the soft-max off
  * (EPIPOLAR.SOFTMAX_ENABLED False: the "attention" sim / K is unbounded) and every call with
  * ET_VARIANT_TILE_EXACT.  Same arguments and results as et_epipolar_forward (rounding differs at the
@@ -271,7 +272,7 @@ int et_residual_gemm(int64_t num_pixels, int32_t C, const float *out, const floa
  * folded into z, i.e. what et_residual_gemm computes from `out` in a second pass -- as a third GEMM of the persistent
  * kernel, on the tile's 32 `out` rows while they are still on chip: `out` is neither written nor re-read (1.07 GB less
  * traffic and one launch less per forward at Config 2).  Applies where the warp-specialised kernel does (C == 256, maps
- * up to 64 x 64, K <= 64, soft-max on, no ET_VARIANT_TILE_CLASSIC / _WS_V2); otherwise the call fails and
+ * up to 96 x 96, K <= 64, soft-max on, no ET_VARIANT_TILE_CLASSIC / _WS_V2); otherwise the call fails and
  * et_epipolar_forward_tiled + et_residual_gemm is the path.
  *   packed_w    : Wf laid out by et_residual_gemm_pack;   bias : (256)
  *   x           : (N,H,W,256)                              attn / corr_pos : as et_epipolar_forward, nullable
