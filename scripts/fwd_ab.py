@@ -14,7 +14,7 @@ g = torch.Generator(device=dev).manual_seed(0)
 ref = torch.randn(128, H, H, C, device=dev, generator=g).relu_()
 src = torch.randn(128, H, H, C, device=dev, generator=g).relu_()
 cam = camera.pair_algebra(P1, P2).to(dev)
-spec = ops.LayerSpec(H=H, W=H, K=K)
+spec = ops.LayerSpec(H=H, W=H, K=K, variant=int(os.environ.get("AB_VARIANT", "0")))
 ws = ops.tile_workspace(spec, 128, C, dev)
 fused = os.environ.get("AB_FUSED") == "1"
 if fused:
