@@ -183,6 +183,8 @@ def default_cfg() -> CfgNode:
     C.EPIPOLAR_AMD.ALIGN_CORNERS = False      # F.grid_sample semantics to reproduce
     C.EPIPOLAR_AMD.VARIANT = 0                # EtLayerDesc.variant bits
     C.EPIPOLAR_AMD.FUSED_EPILOGUE = True      # eval: fold BN and fuse the residual adds in one kernel
+    C.EPIPOLAR_AMD.SHARD_P2P = False          # view-sharded partition: source maps by one all-to-all (each block to the rank that
+                                              # samples it) instead of the all-gather BASELINE.json's north star names (G x the bytes)
     return C
 
 

@@ -95,9 +95,11 @@ class MultiViewPoseModel(nn.Module):
         of this rank's cameras, camera-major (all frames of camera a, then of camera b, ..: `ViewShardExchange`'s pair
         order); KRT / other_KRT (M,3,4): their projection matrices and those of their source views (the ring neighbour,
         owned by another rank).  The trunk runs on the own images only; the source feature maps arrive through ONE
-        all-gather (`parallel.sharded_sources`, channels-last memory as the trunk leaves it), its backward returns
+        all-gather (`parallel.sharded_sources`, channels-last memory as the trunk leaves it; ONE all-to-all with
+        EPIPOLAR_AMD.SHARD_P2P: each map only to the rank that samples it), its backward returns
         d(source maps) to their owners with ONE all-to-all; the weight gradients of the shared network are summed by the
         caller (`parallel.allreduce_gradients` or DDP).  Returns the backbone's 8-tuple."""
+        from .config import amd_knob
         from .parallel import sharded_sources
 
         if self.sharded is None:
@@ -107,7 +109,7 @@ class MultiViewPoseModel(nn.Module):
         net = self.reference
         feature = net.trunk(img)                                            # own cameras only
         nhwc = feature.permute(0, 2, 3, 1).contiguous()                     # (a view when the trunk ran channels_last)
-        other = sharded_sources(nhwc, self.sharded, num_chunks).permute(0, 3, 1, 2)
+        other = sharded_sources(nhwc, self.sharded, num_chunks, p2p=bool(amd_knob(self.cfg, "SHARD_P2P", False))).permute(0, 3, 1, 2)
         if not self.cfg.EPIPOLAR.OTHER_GRAD:
             other = other.detach()
         x, corr_pos, depth, sample_locs = net._fuse(feature, net.epipolar_sampler, other, KRT, other_KRT, camera, other_camera)

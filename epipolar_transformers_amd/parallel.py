@@ -130,6 +130,44 @@ class ViewShardExchange:
                 ranges.append((ci * f + lo, ci * f + hi))
             yield ranges, (chunks[0] if len(chunks) == 1 else torch.cat(chunks))
 
+    def _routes(self):
+        """The ring pairing as an all-to-all: (send_order, send_split, recv_split, recv_slots) for moving every camera block
+        from the rank that OWNS it to the rank whose reference camera samples it -- each block to exactly one rank.
+          send_order : indices into my camera list, grouped by destination rank (group order), inside a destination in the
+                       order of ITS reference cameras;   send_split / recv_split: blocks per rank;
+          recv_slots : for the blocks as they arrive (source rank major), the index of MY reference camera they belong to."""
+        send_order, send_split = [], []
+        for q in self.group_ranks:
+            mine = [self.source_location(cam)[1] for cam in self.cams_of[q] if self.source_location(cam)[0] == self.rank]
+            send_order += mine
+            send_split.append(len(mine))
+        recv_split, recv_slots = [], []
+        for o in self.group_ranks:
+            slots = [ci for ci, cam in enumerate(self.my_cams) if self.source_location(cam)[0] == o]
+            recv_split.append(len(slots))
+            recv_slots += slots
+        return send_order, send_split, recv_split, recv_slots
+
+    def exchange_sources(self, own_maps: torch.Tensor) -> torch.Tensor:
+        """Point-to-point form of gather_sources: ONE all_to_all_single in which every camera block goes only to the rank
+        that samples it -- 1 x the bytes a rank consumes, where the all-gather stages G x (at BASELINE config 5, 1 GiB of
+        maps per rank on 8 ranks, 8 GiB to use one).  Same result as gather_sources, bit for bit (a permutation)."""
+        pg = self._pg()
+        ncam = len(self.my_cams)
+        f = own_maps.shape[0] // ncam
+        per = own_maps.reshape(ncam, f, -1)
+        send_order, send_split, recv_split, recv_slots = self._routes()
+        send = torch.cat([per[i] for i in send_order]) if send_order else per.new_zeros((0, per.shape[2]))
+        recv = torch.empty((sum(recv_split) * f, per.shape[2]), dtype=own_maps.dtype, device=own_maps.device)
+        dist.all_to_all_single(recv, send.contiguous(), output_split_sizes=[n * f for n in recv_split],
+                               input_split_sizes=[n * f for n in send_split], group=pg)
+        if recv_slots == list(range(ncam)):                    # (arrival order = my camera order: the buffer is the result)
+            return recv.view(own_maps.shape)
+        out = torch.empty_like(per)
+        for k, ci in enumerate(recv_slots):
+            out[ci] = recv[k * f:(k + 1) * f]
+        return out.view(own_maps.shape)
+
     def scatter_source_grads(self, grad_src: torch.Tensor) -> torch.Tensor:
         """Backward of gather_sources: route d(source maps) back to the ranks that own those maps.  Every map is
         the source of exactly ONE reference camera (ring pairing), so this is a permutation, not a reduction: one
@@ -171,33 +209,37 @@ class _ShardedSources(torch.autograd.Function):
     those maps (`scatter_source_grads`: a permutation, every map is the source of exactly one reference camera)."""
 
     @staticmethod
-    def forward(ctx, own_maps, exchange):
+    def forward(ctx, own_maps, exchange, p2p=False):
         ctx.exchange = exchange
         # (a view of the freshly allocated receive buffer when the rank owns one camera, a new tensor otherwise: never an
         #  alias of the input, so no copy is needed -- round 3 cloned it: one more pass over the source maps per step)
+        if p2p:
+            return exchange.exchange_sources(own_maps.contiguous())
         return exchange.gather_sources(own_maps.contiguous())
 
     @staticmethod
     def backward(ctx, grad):
-        return ctx.exchange.scatter_source_grads(grad.contiguous()), None
+        return ctx.exchange.scatter_source_grads(grad.contiguous()), None, None
 
 
-def sharded_sources(own_maps: torch.Tensor, exchange: "ViewShardExchange", num_chunks: int = 1) -> torch.Tensor:
+def sharded_sources(own_maps: torch.Tensor, exchange: "ViewShardExchange", num_chunks: int = 1, p2p: bool = False) -> torch.Tensor:
     """Differentiable `gather_sources`: (len(my_cams) * frames, ...) own maps -> same shape, the source map of every
     pair of this rank.  num_chunks > 1 splits the frames of every camera into ranges and exchanges range by range
     (each range its own collective in the forward and in the backward), so that on the GPUs the fused kernel of
-    range i can run while range i + 1 is on the links."""
+    range i can run while range i + 1 is on the links.  p2p: the forward as one all-to-all (`exchange_sources`: every
+    block to the one rank that samples it) instead of the all-gather BASELINE.json's north star names -- same result,
+    1 / G of the bytes staged; the backward is that all-to-all reversed either way."""
     ncam = len(exchange.my_cams)
     f = own_maps.shape[0] // ncam
     num_chunks = max(1, min(int(num_chunks), f))
     if num_chunks == 1:
-        return _ShardedSources.apply(own_maps, exchange)
+        return _ShardedSources.apply(own_maps, exchange, p2p)
     per_cam = own_maps.reshape((ncam, f) + tuple(own_maps.shape[1:]))
     bounds = [(i * f) // num_chunks for i in range(num_chunks + 1)]
     parts = []
     for lo, hi in zip(bounds[:-1], bounds[1:]):
         chunk = per_cam[:, lo:hi].reshape((ncam * (hi - lo),) + tuple(own_maps.shape[1:]))
-        parts.append(_ShardedSources.apply(chunk, exchange).reshape((ncam, hi - lo) + tuple(own_maps.shape[1:])))
+        parts.append(_ShardedSources.apply(chunk, exchange, p2p).reshape((ncam, hi - lo) + tuple(own_maps.shape[1:])))
     return torch.cat(parts, 1).reshape(own_maps.shape)
 
 

@@ -53,6 +53,10 @@ out0, attn0, corr0 = ops.forward_nhwc(spec, own, src_local, cam)
 src_rccl = ex.gather_sources(own)
 assert src_rccl.is_cuda and torch.equal(src_rccl, src_local), "all_gather_into_tensor on RCCL returned other maps"
 
+# --- 1b. the point-to-point form: one all_to_all_single on RCCL, the same maps
+src_p2p = ex.exchange_sources(own)
+assert src_p2p.is_cuda and torch.equal(src_p2p, src_local), "all_to_all_single (exchange_sources) on RCCL returned other maps"
+
 # --- 2. asynchronous chunks (RCCL's stream) feeding the fused kernel (torch's current stream), range by range
 out1 = torch.full_like(out0, float("nan")); attn1 = torch.full_like(attn0, float("nan")); corr1 = torch.full_like(corr0, float("nan"))
 seen = 0
@@ -80,14 +84,14 @@ def loss_through(src_of):
     ((out * w).sum() + (src * src).sum()).backward()
     return a.grad
 
-for chunks in (1, 2):
-    g_rccl = loss_through(lambda a: sharded_sources(a, ex, num_chunks=chunks))
+for chunks, p2p in ((1, False), (2, False), (2, True)):
+    g_rccl = loss_through(lambda a: sharded_sources(a, ex, num_chunks=chunks, p2p=p2p))
     g_loc = loss_through(lambda a: a[idx])
     torch.cuda.synchronize()
     assert torch.isfinite(g_rccl).all()
     # the tile backward sums d(feat_src) with float atomics: reproducible to rounding, not bit for bit
     err = (g_rccl - g_loc).abs().max().item()
-    assert err <= 1e-4 * g_loc.abs().max().item(), (chunks, err)
+    assert err <= 1e-4 * g_loc.abs().max().item(), (chunks, p2p, err)
 # the routing itself (no kernel in between) is a permutation: exact
 a = own.detach().clone().requires_grad_(True)
 (sharded_sources(a, ex, num_chunks=2) * src_local).sum().backward()

@@ -34,6 +34,19 @@ def _worker(rank, world, port, V, frames, errs):
         src = ex.gather_sources(own)
         want = torch.stack([_global_map(fr0 + f, (v + 1) % V) for v in ex.my_cams for f in range(frames)])
         assert torch.equal(src, want), "rank %d got wrong source maps" % rank
+        # point-to-point form (one all-to-all: every block to the one rank that samples it): the same maps, bit for bit
+        assert torch.equal(ex.exchange_sources(own), want), "rank %d: all-to-all exchange differs from the all-gather" % rank
+        # ... and as the autograd step: forward = exchange_sources, backward = the reverse all-to-all
+        from epipolar_transformers_amd.parallel import sharded_sources
+        for p2p in (False, True):
+            for chunks in (1, 2):
+                a = own.clone().requires_grad_(True)
+                out = sharded_sources(a, ex, num_chunks=chunks, p2p=p2p)
+                assert torch.equal(out, want)
+                wgt = torch.stack([_global_map(fr0 + f, v) + 0.25 for v in ex.my_cams for f in range(frames)])
+                (out * wgt).sum().backward()
+                want_g = torch.stack([_global_map(fr0 + f, (c - 1) % V) + 0.25 for c in ex.my_cams for f in range(frames)])
+                assert torch.equal(a.grad, want_g), "rank %d: gradient routing (p2p=%s, chunks=%d)" % (rank, p2p, chunks)
         # chunked / overlappable form: same maps, delivered in frame ranges
         got = torch.empty_like(want)
         seen = 0
@@ -210,7 +223,8 @@ def _sharded_train_worker(rank, world, port, V, frames, chunks, errs):
                              "KEYPOINT.HEATMAP_SIZE", (hs, hs), "KEYPOINT.NUM_PTS", J, "KEYPOINT.SIGMA", 2.0,
                              "DATASETS.IMAGE_SIZE", (size, size), "EPIPOLAR.MERGE", "late", "EPIPOLAR.ATTENTION", "avg",
                              "EPIPOLAR.PARAMETERIZED", ("z",), "EPIPOLAR.ZRESIDUAL", True, "EPIPOLAR.USE_CORRECT_NORMALIZE", True,
-                             "EPIPOLAR.SAMPLESIZE", 8, "EPIPOLAR.SHARE_WEIGHTS", True])
+                             "EPIPOLAR.SAMPLESIZE", 8, "EPIPOLAR.SHARE_WEIGHTS", True,
+                             "EPIPOLAR_AMD.SHARD_P2P", chunks == 2])    # (the chunked case also takes the all-to-all forward)
         ex = ViewShardExchange(world, rank, V)
         torch.manual_seed(5)                                   # the same network and the same GLOBAL batch on every rank
         single = MultiViewPoseModel(cfg)
@@ -281,7 +295,8 @@ def _sharded_train_worker(rank, world, port, V, frames, chunks, errs):
 def test_view_sharded_training_step_matches_single_process_gloo(chunks):
     """north_star: "per-view forward/backward is sharded one-camera-per-GPU ... with RCCL all-gather of source feature
     maps".  World 2 (two cameras per rank), 2 frames x 4 views of epipolarposeR-18: a sharded training step --
-    trunk on the own images, `parallel.sharded_sources` (all-gather forward, all-to-all backward), SyncBN, the summed
+    trunk on the own images, `parallel.sharded_sources` (all-gather forward -- one all-to-all with EPIPOLAR_AMD.SHARD_P2P, the
+    chunked case --, all-to-all backward), SyncBN, the summed
     weight gradients -- reproduces the single-process loss, d feat of every view and the parameter gradients.
     (No multi-GPU curve has been measured; this covers correctness of the path the GPUs run unchanged over RCCL.)"""
     ctx = mp.get_context("spawn")
