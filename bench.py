@@ -357,7 +357,7 @@ def main():
     # is carried beside it against the dense fp32 peak (157.3 TFLOP/s, vector = matrix).  Whether the 50 %-of-HBM target is
     # reachable in EXACT fp32 is computed below from the fp32 MFMA flops the tiles of this very batch issue.
     d_ = spec.desc(n_pairs, C)
-    tile_bits = (_lib.ET_VARIANT_TILE_CLASSIC | _lib.ET_VARIANT_WS_V2 | _lib.ET_VARIANT_WS_SETPRIO | _lib.ET_VARIANT_TILE_EXACT |
+    tile_bits = (_lib.ET_VARIANT_TILE_CLASSIC | _lib.ET_VARIANT_WS_SETPRIO | _lib.ET_VARIANT_TILE_EXACT |
                  _lib.ET_VARIANT_WS_BAND)
     tiled = (args.variant & ~tile_bits) == 0 and int(_lib.load().et_epipolar_forward_workspace_bytes(ctypes.byref(d_))) > 0
     split = tiled and not (args.variant & _lib.ET_VARIANT_TILE_EXACT)
@@ -372,7 +372,7 @@ def main():
                 "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src if traffic else None,
                 "algorithmic_bytes_per_launch": bytes_launch, "kernel_ms": kernel_ms, "kernel_ms_min": k_ms[0],
                 "kernel": ("epipolar_fwd_tile_ws_kernel<%s>: sampling + attention + the z / BN / residual GEMM (et_epipolar_forward_fused)"
-                           % ws_instance(H, W, True) if one_kernel else "epipolar_fwd_tile_ws2_kernel (+ source_planes_kernel)" if ws and (args.variant & _lib.ET_VARIANT_WS_V2)
+                           % ws_instance(H, W, True) if one_kernel
                            else "epipolar_fwd_tile_ws_kernel" if ws else "epipolar_fwd_tile_kernel" if tiled
                            else "epipolar_fwd_kernel") + " (+ tile_keys_kernel, tile_order_kernel)" * bool(tiled),
                 "fp32_flops": flop}

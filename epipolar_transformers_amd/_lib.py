@@ -29,7 +29,6 @@ ET_VARIANT_BWD_UNSORTED = 8192
 ET_VARIANT_NO_TILE = 16384
 ET_VARIANT_TILE_SPLIT = 32768
 ET_VARIANT_TILE_CLASSIC = 65536
-ET_VARIANT_WS_V2 = 131072
 ET_VARIANT_WS_SETPRIO = 262144
 ET_VARIANT_TILE_EXACT = 524288
 ET_VARIANT_WS_BAND = 1048576

@@ -22,8 +22,7 @@ COMMON = ["et_common.h", "epipolar_geometry.h", os.path.join(ROOT, "include", "e
 UNITS = {
     "et_forward.hip": ["kernels_sample_table.inc", "kernels_forward.inc"],
     "et_forward_general.hip": ["et_wave_reduce.h"],
-    "et_forward_tile.hip": ["kernels_forward_tile.inc", "kernels_forward_tile_ws.inc", "kernels_source_planes.inc",
-                            "kernels_forward_tile_ws2.inc", "et_tile_host.h", "et_wave_reduce.h", "et_split_f16.h"],
+    "et_forward_tile.hip": ["kernels_forward_tile.inc", "kernels_forward_tile_ws.inc", "et_tile_host.h", "et_wave_reduce.h", "et_split_f16.h"],
     "et_backward.hip": ["kernels_sample_table.inc", "kernels_backward.inc"],
     "et_backward_tile.hip": ["kernels_forward_tile.inc", "kernels_backward_tile.inc", "et_tile_host.h", "et_wave_reduce.h", "et_split_f16.h"],
     "et_misc.hip": ["kernels_misc.inc"],

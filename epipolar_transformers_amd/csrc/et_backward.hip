@@ -106,7 +106,8 @@ int et_epipolar_backward(const EtLayerDesc *desc, const float *xs, const float *
                                             ? (rows + kWavesPerBlock - 1) / kWavesPerBlock : 16384);
         hipLaunchKernelGGL(bwd_bucket_kernel, dim3(bblocks), dim3(256), 0, st, HW, p.cap, (int)rows, p.ent_count,
                            p.ent_u, p.ent_a, p.ent_b, row_base, row_cursor, csr);
-        // entries per source pixel ordered in LDS (beyond that, or with ET_VARIANT_BWD_UNSORTED: arrival order)
+        // entries per source pixel ordered in LDS (rows with more entries: key range by key range, the same fixed order;
+        // ET_VARIANT_BWD_UNSORTED: arrival order)
         const int max_sort = (desc->variant & ET_VARIANT_BWD_UNSORTED) ? 0 : 1024;
         const unsigned gblocks = (unsigned)((rows + kWavesPerBlock - 1) / kWavesPerBlock);
         const size_t lds = (size_t)kWavesPerBlock * 2 * (max_sort ? max_sort : 1) * sizeof(int);

@@ -5,8 +5,6 @@
 namespace {
 #include "kernels_forward_tile.inc"     // tile_order_kernel, epipolar_fwd_tile_kernel / _list_kernel
 #include "kernels_forward_tile_ws.inc"  // epipolar_fwd_tile_ws_kernel (warp-specialised, persistent): the default
-#include "kernels_source_planes.inc"    // source_planes_kernel (the source maps as split-fp16 planes, once per call)
-#include "kernels_forward_tile_ws2.inc" // epipolar_fwd_tile_ws2_kernel (pre-split source planes; ET_VARIANT_WS_V2 only)
 
 // x rows of the tiles the fused persistent kernel handed to the overflow list (their `out` rows come from the one-block-per-
 // tile kernel): x = feat_ref + bias + out . Wf^T in plain fp32, one block per tile, thread n = output channel n.  Wf is
@@ -74,9 +72,7 @@ size_t et_epipolar_forward_workspace_bytes(const EtLayerDesc *desc)
 {
     if (validate(desc) || !tile_eligible(desc)) return 0;
     const size_t tiles = (size_t)desc->N * (((size_t)desc->H * desc->W + kTilePix - 1) / kTilePix);
-    size_t words = tile_workspace_words(tiles, (size_t)desc->N, (size_t)desc->H * desc->W);
-    if (tile_ws2_eligible(desc)) words += tile_workspace_plane_words((size_t)desc->N, (size_t)desc->H * desc->W);
-    return words * sizeof(int) + 256u;
+    return tile_workspace_words(tiles, (size_t)desc->N, (size_t)desc->H * desc->W) * sizeof(int) + 256u;
 }
 
 size_t et_epipolar_forward_workspace_error_offset(const EtLayerDesc *desc)
@@ -132,7 +128,7 @@ int et_epipolar_forward_tiled(const EtLayerDesc *desc, const float *xs, const fl
     tp.tile_count = w.ovf_count;
     // 1. order every pair's reference pixels by their epipolar line (also clears the overflow counter)
     const int dev = current_device();
-    // (per-pair scale estimates of the source maps: for the split-fp16 GEMMs of the first-generation persistent kernel and
+    // (per-pair scale estimates of the source maps: for the split-fp16 GEMMs of the persistent kernel and
     //  of the one-block-per-tile kernel; ET_VARIANT_TILE_EXACT keeps the latter in exact fp32)
     // soft-max off: exact fp32 throughout, as the header promises (the first GEMM feeds the `== 0 -> -1e10` mask and the
     // "attention" sim / K is unbounded: no fp16 form of the B rows)
@@ -145,48 +141,8 @@ int et_epipolar_forward_tiled(const EtLayerDesc *desc, const float *xs, const fl
     const size_t lds = (size_t)(fwd_tile_array_floats(rows) + rows + kTilePix + 48 + kTilePix * 4) * 4 +
                        (size_t)tp.hw_words * 8 + (kpl == 1 ? (size_t)kTilePix * kWave * 8 : 0);
 #define ET_SET_LDS(KERNEL, BYTES) ET_GRANT_LDS(KERNEL, BYTES, dev)
-    if (tile_ws2_eligible(desc)) {
-        // 2a. (ET_VARIANT_WS_V2) the source maps as split-fp16 planes, one pass over the batch (HBM-bound) ...
-        const long long nrows = (long long)desc->N * HW;
-        const long long pblocks = (nrows + 4 * kPlaneRowsPerWave - 1) / (4 * kPlaneRowsPerWave);
-        if (pblocks > 0x7fffffffLL) return fail("grid too large");
-        hipLaunchKernelGGL(source_planes_kernel, dim3((unsigned)pblocks), dim3(256), 0, st, feat_src, w.planes, w.rowinv, nrows);
-        if (int e = check_launch("et_epipolar_forward_tiled(planes)")) return e;
-        // ... 2b. one persistent block per CU, matrix and vector waves specialised (kernels_forward_tile_ws2.inc) ...
-        TileWs2Params wp;
-        wp.f = p;
-        wp.perm = w.perm;
-        wp.tiles_per_pair = tp.tiles_per_pair;
-        wp.total_tiles = (int)total;
-        wp.rows_cap = tp.rows_cap;
-        wp.ovf_count = w.ovf_count;
-        wp.ovf_list = w.ovf_list;
-        wp.stats = w.stats;
-        wp.err = w.err;
-        wp.segs = w.segs;
-        wp.planes = w.planes;
-        wp.rowinv = w.rowinv;
-        wp.experiment = 0;
-#ifdef ET_WS_PROFILE
-        wp.prof = g_ws_prof;
-        if (const char *e = getenv("ET_WS_EXPERIMENT")) wp.experiment = atoi(e);
-#else
-        wp.prof = nullptr;
-#endif
-        const int cus = device_cus(dev);
-        const unsigned grid = (unsigned)(total < cus ? total : cus);
-        const size_t lds_ws = tile_ws2_lds_bytes(kTileRowsSmall);
-        ET_SET_LDS((epipolar_fwd_tile_ws2_kernel<kTileRowsSmall>), lds_ws);
-        hipLaunchKernelGGL((epipolar_fwd_tile_ws2_kernel<kTileRowsSmall>), dim3(grid), dim3((kWsMatrixWaves + 8) * kWave), lds_ws, st, wp);
-        if (int e = check_launch("et_epipolar_forward_tiled(ws2)")) return e;
-        // ... 2c. and the tiles it left over (row sets beyond its arrays; normally none) one block per tile
-        const unsigned lgrid = (unsigned)(total < 2LL * cus ? total : 2LL * cus);
-        ET_SET_LDS((epipolar_fwd_tile_list_kernel<1, kTileRowsSmall>), lds);
-        hipLaunchKernelGGL((epipolar_fwd_tile_list_kernel<1, kTileRowsSmall>), dim3(lgrid), dim3(256), lds, st, tp);
-        return check_launch("et_epipolar_forward_tiled(list)");
-    }
     if (tile_ws_eligible(desc)) {
-        // 2a'. the first-generation persistent kernel (kernels_forward_tile_ws.inc): the default ...
+        // 2a. the persistent, warp-specialised kernel (kernels_forward_tile_ws.inc): the default ...
         TileWsParams wp;
         wp.f = p;
         wp.perm = w.perm;
@@ -226,7 +182,7 @@ int et_epipolar_forward_tiled(const EtLayerDesc *desc, const float *xs, const fl
                                lds_ws, st, wp);
         }
         if (int e = check_launch("et_epipolar_forward_tiled(ws)")) return e;
-        // ... 2b'. and the tiles it left over one block per tile
+        // ... 2b. and the tiles it left over one block per tile
         const unsigned lgrid = (unsigned)(total < 2LL * cus ? total : 2LL * cus);
         if (rows == kTileRowsLarge) {
             ET_SET_LDS((epipolar_fwd_tile_list_kernel<1, kTileRowsLarge>), lds);
@@ -273,7 +229,7 @@ int et_epipolar_forward_fused(const EtLayerDesc *desc, const float *xs, const fl
     if (!xs || !ys || !steps || !cam || !feat_ref || !feat_src || !packed_w || !bias || !x || !out_scratch)
         return fail("et_epipolar_forward_fused: NULL pointer");
     if (reinterpret_cast<uintptr_t>(packed_w) & 15) return fail("et_epipolar_forward_fused: packed weight must be 16-byte aligned");
-    if (!tile_eligible(desc) || !tile_ws_eligible(desc) || tile_ws2_eligible(desc))
+    if (!tile_eligible(desc) || !tile_ws_eligible(desc))
         return fail("et_epipolar_forward_fused: needs the warp-specialised tile kernel (C == 256, maps up to 96 x 96, K <= 64, "
                     "soft-max on; got C=%d H=%d W=%d K=%d variant=%d): use et_epipolar_forward_tiled + et_residual_gemm",
                     desc->C, desc->H, desc->W, desc->K, desc->variant);

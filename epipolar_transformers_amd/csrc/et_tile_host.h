@@ -48,29 +48,17 @@ bool tile_ws_eligible(const EtLayerDesc *d)
     return (!(d->variant & ET_VARIANT_TILE_CLASSIC) && d->softmax_enabled && d->K <= 64 && d->W >= 2 &&
             tile_rows(d) == kTileRowsSmall) || tile_ws_band(d);
 }
-// second generation (pre-split source planes with exact per-row scales, row masks: kernels_forward_tile_ws2.inc), on
-// request (ET_VARIANT_WS_V2): measured slower than the first on MI355X (profiles/r03_ws2_*), kept as the variant whose
-// arithmetic needs no scale estimate at all
-bool tile_ws2_eligible(const EtLayerDesc *d)
-{
-    return tile_ws_eligible(d) && !tile_ws_band(d) && (d->variant & ET_VARIANT_WS_V2) && d->W <= 64 && d->H <= 64;
-}
-
 // Workspace of the tile forward (all int32, base aligned up to 256 bytes):
 //   header (64 words): [0] overflow count, [1] sticky error word -- at the front, so that their offsets do not depend on
 //   the shape of the call (a workspace is reused across shapes) |
 //   perm[tiles * 32] | overflow list[tiles] | stats[tiles] | scales[4 * N] (float) |
 //   segments[tiles * 32] (float4, 16-byte aligned; in tile order.  Until tile_order_kernel writes them the region of a pair
 //   holds the pair's sort keys: 8 bytes per pixel, tile_keys_kernel) |
-//   band[tiles] (float4: the tile's base line, warp-specialised kernel) | segments by pixel[N * HW] (float4) |
-//   -- warp-specialised kernel, second generation only: --
-//   rowinv[N * HW] (float) | planes[N * HW * 256] (dwords, 256-byte aligned)
+//   band[tiles] (float4: the tile's base line, warp-specialised kernel) | segments by pixel[N * HW] (float4)
 struct TileWorkspace {
     int *perm, *ovf_count, *err, *ovf_list, *stats;
     float *scales;
     float4 *segs, *band, *segs_pix;
-    float *rowinv;
-    unsigned *planes;
 };
 constexpr size_t kTileWorkspaceHeaderWords = 64;
 size_t tile_workspace_words(size_t tiles, size_t pairs, size_t hw)
@@ -78,7 +66,6 @@ size_t tile_workspace_words(size_t tiles, size_t pairs, size_t hw)
     return kTileWorkspaceHeaderWords + tiles * kTilePix + 2 * tiles + 4 * pairs + 4 + 4 * tiles * kTilePix + 4 * tiles +
            4 * pairs * hw;
 }
-size_t tile_workspace_plane_words(size_t pairs, size_t hw) { return pairs * hw + 64 + pairs * hw * 256; }
 TileWorkspace carve_tile_workspace(void *workspace, size_t tiles, size_t pairs, size_t hw)
 {
     TileWorkspace w;
@@ -91,8 +78,6 @@ TileWorkspace carve_tile_workspace(void *workspace, size_t tiles, size_t pairs, 
     w.segs = reinterpret_cast<float4 *>((reinterpret_cast<uintptr_t>(w.scales + 4 * pairs) + 15) & ~(uintptr_t)15);
     w.band = w.segs + tiles * kTilePix;
     w.segs_pix = w.band + tiles;
-    w.rowinv = reinterpret_cast<float *>(w.segs_pix + pairs * hw);
-    w.planes = reinterpret_cast<unsigned *>((reinterpret_cast<uintptr_t>(w.rowinv + pairs * hw) + 255) & ~(uintptr_t)255);
     return w;
 }
 

@@ -216,7 +216,7 @@ class GeneralAttend(torch.autograd.Function):
         return nchw(gq) if ctx.needs_input_grad[0] else None, nchw(gs), nchw(gv), None, None, None
 
 
-_TILE_BITS = (_lib.ET_VARIANT_TILE_SPLIT | _lib.ET_VARIANT_TILE_CLASSIC | _lib.ET_VARIANT_WS_V2 |
+_TILE_BITS = (_lib.ET_VARIANT_TILE_SPLIT | _lib.ET_VARIANT_TILE_CLASSIC |
               _lib.ET_VARIANT_WS_SETPRIO | _lib.ET_VARIANT_TILE_EXACT | _lib.ET_VARIANT_WS_BAND)   # bits that tune the tile path instead of leaving it
 
 

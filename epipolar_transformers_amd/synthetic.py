@@ -81,3 +81,93 @@ def make_features(N, C, H, W, seed=0, relu=True, smooth=False):
     if relu:
         f1, f2 = f1.relu(), f2.relu()
     return f1.contiguous(), f2.contiguous()
+
+
+# ---- camera rigs beyond the ring (the geometry cases of tests/golden/make_golden.py and tests/test_gpu_rigs.py) ------------
+# The ring above keeps the epipole far outside the map: every epipolar line crosses the whole image and the fan of lines
+# is narrow.  The rigs below cover what the reference's geometry code (epipolar.py:340-407) does elsewhere: a fan through
+# 360 degrees (epipole inside the map), an epipole on the rectangle's edge, parallel lines (epipole at infinity, the
+# sign(0) = 0 clamp of epipolar.py:369-373), no usable line at all (identical cameras: every pixel takes the "< 2 valid"
+# placeholder of epipolar.py:395-403), and an H36M-like room rig paired by the reference's nearest-neighbour rule.
+RIGS = ("ring", "epipole_inside", "epipole_border", "rectified_x", "near_rectified_x", "near_rectified_y", "identical", "h36m_room")
+
+# camera centres (mm) of a Human3.6M-like capture room: four cameras near the corners of a ~4 x 10 m floor at ~1.5 m,
+# deliberately not on a circle and not evenly spaced
+_H36M_ROOM_CENTRES = ((1841.0, 4955.0, 1563.0), (1761.0, -5078.0, 1606.0), (-1846.0, 5215.0, 1491.0), (-1794.0, -3722.0, 1574.0))
+
+
+def _projection(K, RT, image_size, sensor=1000.0, jitter=None, rng=None):
+    s = image_size / sensor
+    A = np.array([[s, 0.0, 0.0], [0.0, s, 0.0], [0.0, 0.0, 1.0]])
+    if jitter is not None:
+        ds = 1.0 + jitter[0] * rng.standard_normal()
+        sh = jitter[1] * rng.standard_normal(2)
+        A = np.array([[s * ds, 0.0, sh[0]], [0.0, s * ds, sh[1]], [0.0, 0.0, 1.0]])
+    return A @ K @ RT
+
+
+def nearest_neighbour_pairs(mats):
+    """The reference's test-time pairing (vision/multiview.py:59-83 + data/datasets/multiview_h36m.py:231-238): every
+    camera is the reference once, the camera whose centre is nearest is its source.  mats: (V,3,4) float64."""
+    centres = [-np.linalg.inv(m[:, :3]) @ m[:, 3] for m in mats]
+    src = []
+    for i, c in enumerate(centres):
+        d = [np.linalg.norm(c - o) if j != i else np.inf for j, o in enumerate(centres)]
+        src.append(int(np.argmin(d)))
+    return src
+
+
+def rig_pairs(rig, num_frames=1, image_size=256, seed=0, jitter=None):
+    """P_ref, P_src (N,3,4) float32 of a named rig (RIGS); N = 4 * num_frames except for the two-camera rigs, which
+    yield both orderings of the pair per frame (N = 2 * num_frames)."""
+    if rig == "ring":
+        return make_pairs(num_frames, 4, image_size, seed, jitter)
+    rng = np.random.default_rng(seed)
+    target = np.array([0.0, 0.0, 900.0])
+    p_ref, p_src = [], []
+    for _ in range(num_frames):
+        if rig == "h36m_room":
+            cams = [_projection(*look_at_camera(c, target + rng.normal(0, 50.0, 3)), image_size, jitter=jitter, rng=rng)
+                    for c in _H36M_ROOM_CENTRES]
+            src = nearest_neighbour_pairs(cams)
+            for v in range(4):
+                p_ref.append(cams[v])
+                p_src.append(cams[src[v]])
+            continue
+        # two cameras A, B sharing one rotation (look-at from A)
+        a = np.array([5000.0 * math.cos(0.3), 5000.0 * math.sin(0.3), 1500.0])
+        K, RT = look_at_camera(a, target)
+        R = RT[:, :3]
+        right, down, fwd = R[0], R[1], R[2]
+        if rig == "epipole_inside":
+            # B stands in front of A, a little off its axis: A's centre projects INSIDE B's image and vice versa is
+            # behind B (negative depth, still a finite epipole inside the image after the division)
+            b = a + 1200.0 * fwd + 90.0 * right - 60.0 * down
+        elif rig == "epipole_border":
+            # the offset that puts the epipole on the rectangle's left edge: x_e = s (cx + f dx / dz) = xmin = 1.5
+            s = image_size / 1000.0
+            dz = 1500.0
+            dx = (1.5 / s - K[0, 2]) * dz / K[0, 0]
+            b = a - dz * fwd - dx * right + 40.0 * down       # A is dz in FRONT of B, at camera-x = dx, camera-y = -40 mm
+        elif rig == "rectified_x":
+            # pure sideways baseline: the epipole's third coordinate is exactly 0 in float32, the division of
+            # epipolar.py:348 yields (+-inf, inf|nan) and every comparison of :388-393 fails -- all pixels invalid
+            b = a + 400.0 * right
+        elif rig == "near_rectified_x":
+            b = a + 400.0 * right + 0.4 * fwd                  # epipole ~1e6 px away: horizontal lines, |l2.x| tiny
+        elif rig == "near_rectified_y":
+            b = a + 400.0 * down + 0.4 * fwd                   # the same with vertical lines (y-major tiles)
+        elif rig == "identical":
+            b = a.copy()
+        else:
+            raise ValueError("unknown rig %r (have %s)" % (rig, ", ".join(RIGS)))
+        RTb = np.concatenate([R, (-R @ b)[:, None]], 1)
+        pa = _projection(K, RT, image_size, jitter=jitter, rng=rng)
+        if rig in ("rectified_x", "near_rectified_x", "near_rectified_y", "identical"):
+            pa, pb = _projection(K, RT, image_size), _projection(K, RTb, image_size)   # (a rectified pair shares its crop)
+        else:
+            pb = _projection(K, RTb, image_size, jitter=jitter, rng=rng)
+        p_ref += [pa, pb]
+        p_src += [pb, pa]
+    to32 = lambda x: torch.from_numpy(np.stack(x)).float()
+    return to32(p_ref), to32(p_src)

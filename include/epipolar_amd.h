@@ -79,7 +79,7 @@ typedef struct EtLayerDesc {
 #define ET_VARIANT_NO_TILE 16384  /* host wrappers: do not route C == 256 calls to et_epipolar_forward_tiled */
 #define ET_VARIANT_TILE_SPLIT 32768 /* et_epipolar_forward_tiled, testing: 64-row tiles, so that tiles overflow and split */
 #define ET_VARIANT_TILE_CLASSIC 65536 /* et_epipolar_forward_tiled: the one-block-per-tile kernel (split-fp16 GEMMs, exact-fp32 redo of overflowing tiles) instead of the warp-specialised persistent one */
-#define ET_VARIANT_WS_V2 131072   /* et_epipolar_forward_tiled: the second-generation warp-specialised kernel (source maps pre-split into fp16 planes under exact per-row scales; kernels_forward_tile_ws2.inc) instead of the first */
+/* (bit 131072 was ET_VARIANT_WS_V2, a second-generation persistent kernel on pre-split source planes: measured slower in rounds 3-4 (profiles/r03_ws2_vs_v1_timing.txt), retired in round 5; the bit is reserved and now selects nothing) */
 #define ET_VARIANT_WS_SETPRIO 262144 /* warp-specialised kernel (first generation), tuning: s_setprio 1 on the matrix waves */
 #define ET_VARIANT_WS_BAND 1048576 /* et_epipolar_forward_tiled / _fused, testing: the persistent kernel's instance for maps above 64 x 64 (288-row arrays, slot table over the tile's band) also for smaller maps */
 #define ET_VARIANT_TILE_EXACT 524288 /* et_epipolar_forward_tiled, one-block-per-tile kernel: both GEMMs in exact fp32 (v_mfma_f32_32x32x2_f32) instead of split-fp16 products */
@@ -129,10 +129,7 @@ int et_epipolar_forward(const EtLayerDesc *desc, const float *xs, const float *y
  * two, split into fp16 hi + lo at the point of use and every converted value is range-checked), vector
  * waves do the geometry / row-set / soft-max work of the neighbouring tiles meanwhile (two instances:
  * 256-row arrays up to 64 x 64 maps; 288-row arrays and a slot table over the tile's band above).
- * ET_VARIANT_WS_V2 selects a second form of that kernel that first rewrites the source maps as
- * split-fp16 planes (one dword ( hi | lo << 16 ) per value, one exact power-of-two scale per pixel row;
- * kept in the workspace) -- measured slower on MI355X, not the default.  Other shapes (maps above
- * 96 x 96, K > 64) run one block per tile with the same split-fp16 GEMMs.  A tile with a value beyond
+ * Other shapes (maps above 96 x 96, K > 64) run one block per tile with the same split-fp16 GEMMs.  A tile with a value beyond
  * fp16's range is redone in exact fp32, and so is every call with the soft-max off
  * (EPIPOLAR.SOFTMAX_ENABLED False: the "attention" sim / K is unbounded) and every call with
  * ET_VARIANT_TILE_EXACT.  Same arguments and results as et_epipolar_forward (rounding differs at the
@@ -143,14 +140,13 @@ int et_epipolar_forward(const EtLayerDesc *desc, const float *xs, const float *y
  *               (et_epipolar_forward_workspace_error_offset(desc) = 4 bytes in, whatever the shape, so
  *               that a workspace reused across shapes keeps ONE error word: the kernels only ever OR
  *               bits into it; bit 0 / bit 1: a wave of a persistent kernel gave up waiting at an
- *               internal barrier -- the results of that call are invalid.  Such barriers exist in the
- *               ET_VARIANT_WS_V2 kernel (bit 0) and in front of the third GEMM of
- *               et_epipolar_forward_fused (bit 1); the default kernel's waves never wait on each other
+ *               internal barrier -- the results of that call are invalid.  Such a barrier exists in
+ *               front of the third GEMM of et_epipolar_forward_fused (bit 1; bit 0 belonged to a kernel
+ *               retired in round 5); the default kernel's waves never wait on each other
  *               outside the hardware barrier.  The library never synchronises, so the caller reads the word when
  *               it synchronises anyway: ops.check_tile_errors in the Python binding) -- followed by
  *               the per-pair pixel order, the overflow-tile list, per-pair scales, the epipolar
- *               segments in tile order, one base line per tile and the segments by pixel (with
- *               ET_VARIANT_WS_V2 also the source planes, as large as feat_src), and
+ *               segments in tile order, one base line per tile and the segments by pixel, and
  *                 - one int32 of statistics per tile ( U | groups << 16 : size of the tile's
  *                   source-row set, number of groups it was split into) starting
  *                   et_epipolar_forward_workspace_stats_offset(desc) bytes in, in tile order
@@ -272,7 +268,7 @@ int et_residual_gemm(int64_t num_pixels, int32_t C, const float *out, const floa
  * folded into z, i.e. what et_residual_gemm computes from `out` in a second pass -- as a third GEMM of the persistent
  * kernel, on the tile's 32 `out` rows while they are still on chip: `out` is neither written nor re-read (1.07 GB less
  * traffic and one launch less per forward at Config 2).  Applies where the warp-specialised kernel does (C == 256, maps
- * up to 96 x 96, K <= 64, soft-max on, no ET_VARIANT_TILE_CLASSIC / _WS_V2); otherwise the call fails and
+ * up to 96 x 96, K <= 64, soft-max on, no ET_VARIANT_TILE_CLASSIC); otherwise the call fails and
  * et_epipolar_forward_tiled + et_residual_gemm is the path.
  *   packed_w    : Wf laid out by et_residual_gemm_pack;   bias : (256)
  *   x           : (N,H,W,256)                              attn / corr_pos : as et_epipolar_forward, nullable

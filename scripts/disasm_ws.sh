@@ -2,7 +2,7 @@
 # development: disassemble a kernel of et_forward_tile.o into /tmp/dis/<name>.s    usage: disasm_ws.sh [mangled-name-fragment]
 mkdir -p /tmp/dis && cd /tmp/dis || exit 1
 OBJ=${OBJ:-/root/repo/epipolar_transformers_amd/lib/obj/et_forward_tile.o}
-FRAG=${1:-ws2_kernelILi256E}
+FRAG=${1:-tile_ws_kernelILi256E}
 cp "$OBJ" ft.o
 /opt/rocm/lib/llvm/bin/llvm-objdump --offloading ft.o > /dev/null 2>&1
 mv ft.o.0.hipv4-amdgcn-amd-amdhsa--gfx950 ft.co; rm -f ft.o.0.host*

@@ -49,7 +49,7 @@ def events_ms(fn, reps=20, warm=3):
 def main():
     dev = torch.device("cuda:0")
     lib = _lib.load()
-    CL, V2, PRIO = _lib.ET_VARIANT_TILE_CLASSIC, _lib.ET_VARIANT_WS_V2, _lib.ET_VARIANT_WS_SETPRIO
+    CL, PRIO = _lib.ET_VARIANT_TILE_CLASSIC, _lib.ET_VARIANT_WS_SETPRIO
     cases = [(2, 64, 64, True, 4), (4, 64, 64, False, 4), (3, 32, 128, True, 4), (2, 48, 33, True, 4),
              (4, 16, 16, True, 8), (4, 96, 64, True, 4), (1, 64, 64, True, 4), (5, 64, 20, True, 4), (128, 64, 64, True, 4)]
     for (N, hw, K, sm, views) in cases:
@@ -71,7 +71,7 @@ def main():
               "  res_base %.1e" % (N, hw, hw, K, sm, (o1 - o2).abs().max().item(), o1.abs().max().item(),
                                    (a1 - a2).abs().max().item(), (c1 != c2).any(-1).float().mean().item(),
                                    (b1 - b2).abs().max().item()), flush=True)
-        for nm, v in (("classic", CL), ("ws v2", V2)):
+        for nm, v in (("classic", CL),):
             o3, a3, c3, b3 = ops.forward_nhwc(dataclasses.replace(spec, variant=v), ref, src, cam, res_bias=bias,
                                               want_res_base=True)
             print("    default vs %-8s out %.2e attn %.2e corr %.4f base %.1e  (bit-equal: %s)" % (
@@ -80,7 +80,7 @@ def main():
                 flush=True)
         if N < 64:
             continue
-        for nm, v in (("per-pixel", _lib.ET_VARIANT_NO_TILE), ("classic", CL), ("ws (default)", 0), ("ws v2", V2),
+        for nm, v in (("per-pixel", _lib.ET_VARIANT_NO_TILE), ("classic", CL), ("ws (default)", 0),
                       ("ws prio", PRIO)):
             sp = dataclasses.replace(spec, variant=v)
             m1, lo1 = events_ms(lambda: ops.forward_nhwc(sp, ref, src, cam, res_bias=bias, want_res_base=True))

