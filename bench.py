@@ -49,6 +49,10 @@ def parse():
     ap.add_argument("--partition", choices=["frames", "views"], default="frames")
     ap.add_argument("--exchange-chunks", type=int, default=4,
                     help="view partition: all-gather the source maps in this many frame ranges, overlapped with the kernel")
+    ap.add_argument("--p2p", action="store_true",
+                    help="view partition: exchange the source maps with chunked all-to-alls in which every camera block goes "
+                         "only to the rank that samples it (1 x the bytes) instead of the all-gather BASELINE.json's north star "
+                         "names (G x the bytes staged); same chunking / overlap, same results")
     ap.add_argument("--frames", type=int, default=32, help="frames per GPU (4 views each)")
     ap.add_argument("--views", type=int, default=4)
     ap.add_argument("--hw", type=int, default=64)
@@ -181,7 +185,8 @@ def main():
         range i runs while ranges i+1.. are still on the xGMI links."""
         cam = camera.pair_algebra(P_ref_pin, P_src_pin).pin_memory().to(dev, non_blocking=True)
         xs = []
-        for ranges, src_chunk in exchange.gather_sources_chunked(feat_own, args.exchange_chunks):
+        chunks = (exchange.exchange_sources_chunked if args.p2p else exchange.gather_sources_chunked)(feat_own, args.exchange_chunks)
+        for ranges, src_chunk in chunks:
             # contiguous frame ranges: views of the reference maps / camera algebra, no index gather in the timed step
             if len(ranges) == 1:
                 ref_c, cam_c = feat_ref[ranges[0][0]:ranges[0][1]], cam[ranges[0][0]:ranges[0][1]]
@@ -361,10 +366,12 @@ def main():
                  _lib.ET_VARIANT_WS_BAND)
     tiled = (args.variant & ~tile_bits) == 0 and int(_lib.load().et_epipolar_forward_workspace_bytes(ctypes.byref(d_))) > 0
     split = tiled and not (args.variant & _lib.ET_VARIANT_TILE_EXACT)
-    ws = split and not (args.variant & _lib.ET_VARIANT_TILE_CLASSIC) and K <= 64 and H <= 64 and W <= 64
+    # (the persistent kernel's predicate, et_tile_host.h tile_ws_eligible: K <= 64, maps up to 96 x 96, soft-max on, no CLASSIC bit)
+    ws = split and not (args.variant & _lib.ET_VARIANT_TILE_CLASSIC) and K <= 64 and 2 <= W and max(H, W) <= 96
     traffic = measured_hbm_traffic(C, H, W, K, n_pairs, one_kernel)
     traffic_src = "profiles/%s (rocprofv3 --pmc pass, committed)" % ("fwd_fused_pmc_latest.json" if one_kernel else "fwd_pmc_latest.json")
-    flop = {"achieved": achieved_tf, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved_tf / FP32_PEAK_TFLOPS,
+    # (an algorithmic RATE, not a fraction of a peak: the products run on the fp16 matrix cores, three MFMAs per fp32 product)
+    flop = {"achieved": achieved_tf, "unit": "TFLOP/s of algorithmic fp32 flops (12 K C H W per pair [+ 2 C^2 H W])",
             "algorithmic_flops_per_launch": flops_launch,
             "arithmetic": "split-fp16 MFMA (v_mfma_f32_32x32x16_f16 / 16x16x32, ~22 significant bits per product), fp32 accumulate" if split
             else ("v_mfma_f32_32x32x2_f32" if tiled else "fp32 VALU")}
@@ -373,9 +380,9 @@ def main():
                 "algorithmic_bytes_per_launch": bytes_launch, "kernel_ms": kernel_ms, "kernel_ms_min": k_ms[0],
                 "kernel": ("epipolar_fwd_tile_ws_kernel<%s>: sampling + attention + the z / BN / residual GEMM (et_epipolar_forward_fused)"
                            % ws_instance(H, W, True) if one_kernel
-                           else "epipolar_fwd_tile_ws_kernel" if ws else "epipolar_fwd_tile_kernel" if tiled
+                           else "epipolar_fwd_tile_ws_kernel<%s>" % ws_instance(H, W, False) if ws else "epipolar_fwd_tile_kernel" if tiled
                            else "epipolar_fwd_kernel") + " (+ tile_keys_kernel, tile_order_kernel)" * bool(tiled),
-                "fp32_flops": flop}
+                "algorithmic_flop_rate": flop}
     if one_kernel:
         # the sample + attention kernel alone (et_epipolar_forward_tiled: what writes `out`; the kernel rounds 1-3 reported
         # here and the one the 50 %-of-HBM target of BASELINE.json names), same algorithmic bytes
@@ -427,6 +434,10 @@ def main():
                                "z+BN+residual, eval" % ("configs[1]: " if (V, frames, C, H, K) == (4, 32, 256, 64, 64)
                                                         else "", V, frames, n_pairs, C, H, W, K),
                    "partition": args.partition, "layout": "NHWC (channels_last)", "pairs_per_gpu": n_pairs,
+                   "exchange": (None if exchange is None else
+                                "%d chunked %s per step, overlapped with the kernel" %
+                                (args.exchange_chunks, "all_to_all_single (every block to the one rank that samples it, 1 x the bytes)"
+                                 if args.p2p else "all_gather_into_tensor (G x the bytes staged)")),
                    "variant": args.variant,
                    "launch": "one hipGraph per step (host algebra every step, outside the graph)" if graphed
                              else "kernel by kernel from Python",
@@ -445,8 +456,11 @@ def main():
         result["extra"]["residual_gemm"] = rg
 
     ops.check_tile_errors()                  # the sticky device-side error word of the tile forward (synchronises)
-    if rank == 0 and not args.no_other_configs and (V, frames, C, H, K) == (4, 32, 256, 64, 64):
+    if rank == 0 and exchange is None and C == 256:
         del gout, attn_fwd
+        gout = attn_fwd = None
+        result["extra"]["train_step"] = train_step(dev, H, W, C, K, feat_ref, feat_src, P_ref, P_src)
+    if rank == 0 and not args.no_other_configs and (V, frames, C, H, K) == (4, 32, 256, 64, 64):
         result["extra"]["config4"] = other_config(dev, hw=96, samples=64, views=4, frames=32,
                                                   name="configs[3] head: 96x96, K=64 (ResNet-152 384x384), 4 views x 32 frames = 128 pairs")
         result["extra"]["config5"] = other_config(dev, hw=128, samples=128, views=8, frames=8,
@@ -465,6 +479,68 @@ def main():
         print(json.dumps(result))
     if world > 1:
         dist.destroy_process_group()
+
+
+def train_step(dev, H, W, C, K, feat_ref, feat_src, P_ref, P_src, reps=8):
+    """One TRAINING step of the layer on the headline batch (north_star: "per-view forward/backward"; the reference's step is
+    forward + loss + backward, engine/trainer.py:72-76): `Epipolar.forward_fused` in train mode -- the two-kernel forward
+    that keeps `out` and the attention for autograd (ops.EpipolarAttend), z (1x1 convolution) + batch-norm with BATCH
+    statistics + both residual adds as stock torch ops (what SURVEY.md 2.2 allows), then the backward of all of it with a
+    given d(loss)/dx: torch's for the epilogue, the MFMA tile backward (re-using the saved attention) for the layer -- with
+    gradients for both feature maps and the four parameters.  HIP events around whole steps; the roofline figure is the
+    layer's forward + backward algorithmic bytes over the step time."""
+    from epipolar_transformers_amd import default_cfg
+    from epipolar_transformers_amd.epipolar import Epipolar
+
+    cfg = default_cfg()
+    cfg.merge_from_list(["KEYPOINT.HEATMAP_SIZE", (H, W), "KEYPOINT.NFEATS", C, "EPIPOLAR.SAMPLESIZE", K,
+                         "EPIPOLAR.ATTENTION", "avg", "EPIPOLAR.PARAMETERIZED", ("z",), "EPIPOLAR.ZRESIDUAL", True,
+                         "EPIPOLAR.USE_CORRECT_NORMALIZE", True, "DATASETS.IMAGE_SIZE", (4 * H, 4 * W)])
+    torch.manual_seed(0)
+    mod = Epipolar(cfg=cfg).to(dev).train()
+    with torch.no_grad():
+        mod.bn.weight.normal_(1, 0.1)
+        mod.bn.bias.normal_(0, 0.1)
+    n = feat_ref.shape[0]
+    a1 = feat_ref.permute(0, 3, 1, 2).detach().requires_grad_(True)          # logical NCHW over channels-last memory
+    a2 = feat_src.permute(0, 3, 1, 2).detach().requires_grad_(True)
+    gx = torch.randn(n, H, W, C, device=dev).permute(0, 3, 1, 2)
+
+    def fwd():
+        return mod.forward_fused(a1, a2, P_ref, P_src)[0]
+
+    def step():
+        a1.grad = a2.grad = None
+        mod.zero_grad(set_to_none=True)
+        fwd().backward(gx)
+
+    def timed(fn):
+        for _ in range(3):
+            fn()
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+        torch.cuda.synchronize()
+        for a, b in ev:
+            a.record()
+            fn()
+            b.record()
+        torch.cuda.synchronize()
+        return sum(a.elapsed_time(b) for a, b in ev) / reps
+
+    step_ms = timed(step)
+    with torch.no_grad():
+        pass
+    fwd_ms = timed(lambda: fwd())                                            # (graph built, not run backward)
+    a1.grad = a2.grad = None
+    mod.zero_grad(set_to_none=True)
+    fb = algorithmic_bytes_per_pair(C, H, W, K) * n
+    bb = (5 * C * H * W * 4 + K * H * W * 4) * n
+    return {"ms_per_step": step_ms, "pair_views_per_s": n / (step_ms * 1e-3), "forward_ms": fwd_ms,
+            "backward_ms": step_ms - fwd_ms, "pairs": n,
+            "algorithmic_bytes": fb + bb, "frac_of_hbm_peak": (fb + bb) / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "kernels": "forward: tile_keys + tile_order + epipolar_fwd_tile_ws_kernel (out, attention kept for autograd), then torch "
+                       "conv1x1 + batch_norm (batch statistics) + 2 adds; backward: torch through the epilogue, then tile_keys + "
+                       "tile_order + epipolar_bwd_tile_kernel (saved attention)",
+            "note": "train mode, gradients w.r.t. feat_ref, feat_src, z.weight, z.bias, bn.weight, bn.bias; d(loss)/dx given"}
 
 
 def ws_instance(h, w, fused):

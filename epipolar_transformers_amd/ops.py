@@ -6,6 +6,7 @@ caller hands NCHW-contiguous memory."""
 from __future__ import annotations
 
 import ctypes
+import threading
 from dataclasses import dataclass
 
 import numpy as np
@@ -293,7 +294,16 @@ def forward_fused_nhwc(spec: LayerSpec, ref: torch.Tensor, src: torch.Tensor, ca
         raise ValueError("feature maps %s / %s do not match the layer's %dx%d x 256" % (tuple(ref.shape), tuple(src.shape), spec.H, spec.W))
     if cam.shape != (n, _lib.ET_CAM_STRIDE) or not cam.is_contiguous():
         raise ValueError("cam must be a contiguous (N,%d) tensor" % _lib.ET_CAM_STRIDE)
-    assert ref.is_contiguous() and src.is_contiguous() and bias.is_contiguous() and bias.numel() == c
+    need = int(_lib.load().et_residual_gemm_packed_bytes())
+    if packed.numel() < need or not packed.is_contiguous() or packed.device != ref.device:
+        raise ValueError("packed holds %d bytes on %s: the kernel reads %d on %s (ops.residual_gemm_pack)" %
+                         (packed.numel(), packed.device, need, ref.device))
+    if not (ref.is_contiguous() and src.is_contiguous()):
+        raise ValueError("feat_ref / feat_src must be contiguous (N,H,W,C) tensors")
+    if bias.numel() != c or not bias.is_contiguous() or bias.device != ref.device:
+        raise ValueError("bias must be a contiguous float32 vector of %d values on %s" % (c, ref.device))
+    if workspace is not None and (workspace.device != ref.device or workspace.dtype != torch.uint8):
+        raise ValueError("workspace must be a uint8 tensor on %s" % (ref.device,))
     xs, ys, steps = spec.constants(ref.device)
     x = _empty(None, like=ref)
     # `out`: requested -> a fresh tensor; otherwise scratch for the rows of overflow tiles only (normally none is written),
@@ -312,6 +322,8 @@ def forward_fused_nhwc(spec: LayerSpec, ref: torch.Tensor, src: torch.Tensor, ca
                                                  _stream(ref)), "et_epipolar_forward_fused")
         if POISON_OUTPUTS:
             check_tile_errors(workspace=ws)
+        else:
+            _poll_tile_error(ws)
     return (x, attn, corr, out) if want_out else (x, attn, corr)
 
 
@@ -321,12 +333,14 @@ _workspaces = {}
 def _workspace(device, nbytes: int, tag: str = "bwd") -> torch.Tensor:
     """Device scratch the library asks for (it allocates nothing itself): the pixel order / overflow list / tile
     statistics of the tile kernels (tag "fwd", 2.3 MB at Config 2) and the coefficient entries of the gather-form
-    backward (tag "bwd", 3.8 GB at Config 2 -- sized for 288 GB of HBM).  One buffer per (device, stream, tag), grown
-    on demand: all use is stream-ordered on the stream it is keyed by, so concurrent streams / DataParallel threads
-    never share one.  release_workspaces() drops them."""
+    backward (tag "bwd", 3.8 GB at Config 2 -- sized for 288 GB of HBM).  One buffer per (device, stream, tag, host
+    thread), grown on demand: all use is stream-ordered on the stream it is keyed by, and two host threads that launch
+    on the SAME device and stream (nn.DataParallel replicas pinned to one GPU) get buffers of their own -- the cache is
+    the package's only process-wide mutable state, and no two callers ever write the same entry.
+    release_workspaces() drops them."""
     dev = torch.device(device)
     key = (dev.type, dev.index if dev.index is not None else torch.cuda.current_device(),
-           torch.cuda.current_stream(dev).cuda_stream, tag)
+           torch.cuda.current_stream(dev).cuda_stream, tag, threading.get_ident())
     buf = _workspaces.get(key)
     if buf is None or buf.numel() < nbytes:
         # zero-initialised ONCE (include/epipolar_amd.h): the tile forward keeps a sticky error word in it
@@ -342,25 +356,67 @@ def _read_tile_error(buf: torch.Tensor) -> int:
     return int(buf[base + _TILE_ERROR_OFFSET: base + _TILE_ERROR_OFFSET + 4].view(torch.int32).item())
 
 
-def check_tile_errors(spec: "LayerSpec" = None, n: int = None, c: int = 256, workspace: torch.Tensor = None):
+_TILE_ERROR_TEXT = ("the tile forward reported device-side error bits 0x%x (bit 1: a matrix wave of et_epipolar_forward_fused gave "
+                    "up at the barrier in front of its third GEMM; the results of that call are invalid)")
+
+
+def _clear_tile_error(buf: torch.Tensor):
+    base = (-buf.data_ptr()) % 256
+    buf[base + _TILE_ERROR_OFFSET: base + _TILE_ERROR_OFFSET + 4].zero_()
+
+
+def check_tile_errors(spec: "LayerSpec" = None, n: int = None, c: int = 256, workspace: torch.Tensor = None, reset: bool = True):
     """Read the sticky error word the tile forward keeps in its workspace (the library never synchronises, so this is
     where a device-side fault surfaces: it synchronises).  Without arguments: every cached forward workspace; with
     `workspace`: that one (spec / n / c are accepted for compatibility; the word sits in the workspace header, at the same
-    offset for every shape).  Raises EpipolarAmdError.  Called after every tile forward when POISON_OUTPUTS is set
-    (the test suite) and once per bench.py run."""
+    offset for every shape).  Raises EpipolarAmdError; with `reset` (default) the word is cleared once it has been
+    reported, so that later calls are judged on their own.  Called after every tile forward when POISON_OUTPUTS is set
+    (the test suite) and once per bench.py run; the product path (forward_fused_nhwc) polls the word without
+    synchronising, see _poll_tile_error."""
     bufs = [workspace] if workspace is not None else [buf for key, buf in _workspaces.items() if key[3] == "fwd"]
     for buf in bufs:
         if buf is None or buf.numel() < 512:
             continue
         word = _read_tile_error(buf)
         if word:
-            raise _lib.EpipolarAmdError("the tile forward reported device-side error bits 0x%x (bit 0: a wave gave up "
-                                        "at the kernel's internal barrier; the results of that call are invalid)" % word)
+            if reset:
+                _clear_tile_error(buf)
+            raise _lib.EpipolarAmdError(_TILE_ERROR_TEXT % word)
+
+
+_TILE_ERROR_POLL_EVERY = 16
+_error_probes = {}      # workspace data_ptr -> [calls since the last probe, pinned host word | None, event | None]
+
+
+def _poll_tile_error(buf: torch.Tensor):
+    """The product path's check of the sticky error word WITHOUT a host synchronisation: every 16th one-kernel forward on a
+    workspace enqueues a 4-byte device-to-host copy of the word behind the kernel (pinned memory, non-blocking) and an
+    event; a later call that finds the event complete reads the host copy and raises (and clears the word) if a wave
+    of an EARLIER call gave up at its barrier.  A fault therefore surfaces at most ~32 calls late instead of never;
+    check_tile_errors() is the immediate, synchronising form."""
+    st = _error_probes.setdefault(buf.data_ptr(), [0, None, None])
+    if st[2] is not None and st[2].query():
+        word = int(st[1].item())
+        st[1] = st[2] = None
+        if word:
+            _clear_tile_error(buf)
+            raise _lib.EpipolarAmdError((_TILE_ERROR_TEXT % word) + " -- reported by the asynchronous poll: the faulty call is "
+                                        "one of the last %d on this workspace" % (2 * _TILE_ERROR_POLL_EVERY))
+    st[0] += 1
+    if st[2] is None and st[0] >= _TILE_ERROR_POLL_EVERY:
+        st[0] = 0
+        base = (-buf.data_ptr()) % 256
+        host = torch.empty(1, dtype=torch.int32).pin_memory()
+        host.copy_(buf[base + _TILE_ERROR_OFFSET: base + _TILE_ERROR_OFFSET + 4].view(torch.int32), non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(buf.device))
+        st[1], st[2] = host, ev
 
 
 def release_workspaces():
     """Drop every cached scratch buffer (e.g. the 3.8 GB of the gather-form backward after a training phase)."""
     _workspaces.clear()
+    _error_probes.clear()
 
 
 def tile_workspace(spec: LayerSpec, n: int, c: int, device) -> torch.Tensor:

@@ -168,6 +168,42 @@ class ViewShardExchange:
             out[ci] = recv[k * f:(k + 1) * f]
         return out.view(own_maps.shape)
 
+    def exchange_sources_chunked(self, own_maps: torch.Tensor, num_chunks: int):
+        """Overlappable form of exchange_sources, the point-to-point counterpart of gather_sources_chunked: the frames of
+        every camera are split in `num_chunks` ranges and each range travels as its own asynchronous all_to_all_single in
+        which a camera block goes only to the rank that samples it (1 x the bytes, where the all-gather stages G x).  Yields
+        `(ranges, source_maps)` per chunk exactly as gather_sources_chunked does -- the two are interchangeable."""
+        pg = self._pg()
+        ncam = len(self.my_cams)
+        f = own_maps.shape[0] // ncam
+        num_chunks = max(1, min(num_chunks, f))
+        bounds = [(i * f) // num_chunks for i in range(num_chunks + 1)]
+        rest = tuple(own_maps.shape[1:])
+        per_cam = own_maps.view((ncam, f) + rest)
+        send_order, send_split, recv_split, recv_slots = self._routes()
+        inflight = []
+        for lo, hi in zip(bounds[:-1], bounds[1:]):
+            n = hi - lo
+            if len(send_order) == 1:
+                send = per_cam[send_order[0], lo:hi]                       # contiguous: no staging copy
+            else:
+                send = torch.cat([per_cam[i, lo:hi] for i in send_order]) if send_order else own_maps.new_zeros((0,) + rest)
+            recv = torch.empty((sum(recv_split) * n,) + rest, dtype=own_maps.dtype, device=own_maps.device)
+            work = dist.all_to_all_single(recv, send.contiguous(), output_split_sizes=[c * n for c in recv_split],
+                                          input_split_sizes=[c * n for c in send_split], group=pg, async_op=True)
+            inflight.append((lo, hi, recv, work))
+        for lo, hi, recv, work in inflight:
+            work.wait()
+            n = hi - lo
+            ranges = [(ci * f + lo, ci * f + hi) for ci in range(ncam)]
+            if recv_slots == list(range(ncam)):                            # arrival order = my camera order
+                yield ranges, recv
+            else:
+                blocks = [None] * ncam
+                for k, ci in enumerate(recv_slots):
+                    blocks[ci] = recv[k * n:(k + 1) * n]
+                yield ranges, torch.cat(blocks)
+
     def scatter_source_grads(self, grad_src: torch.Tensor) -> torch.Tensor:
         """Backward of gather_sources: route d(source maps) back to the ranks that own those maps.  Every map is
         the source of exactly ONE reference camera (ring pairing), so this is a permutation, not a reduction: one
@@ -211,11 +247,17 @@ class _ShardedSources(torch.autograd.Function):
     @staticmethod
     def forward(ctx, own_maps, exchange, p2p=False):
         ctx.exchange = exchange
-        # (a view of the freshly allocated receive buffer when the rank owns one camera, a new tensor otherwise: never an
-        #  alias of the input, so no copy is needed -- round 3 cloned it: one more pass over the source maps per step)
         if p2p:
             return exchange.exchange_sources(own_maps.contiguous())
-        return exchange.gather_sources(own_maps.contiguous())
+        out = exchange.gather_sources(own_maps.contiguous())
+        # With one camera per rank the result is a slice of the G x receive buffer of the all-gather, and the fused op saves
+        # it for its backward: as a view it would keep the WHOLE buffer alive through forward and backward (8 GiB held to use
+        # 1 GiB at BASELINE config 5 on 8 ranks).  Copy the slice out and let the buffer go; with more cameras per rank
+        # gather_sources has already concatenated into a tensor of its own.  (p2p stages 1 x and needs no copy.)
+        base = out._base
+        if base is not None and base.numel() > out.numel():
+            out = out.clone()
+        return out
 
     @staticmethod
     def backward(ctx, grad):

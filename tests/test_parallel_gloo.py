@@ -57,6 +57,17 @@ def _worker(rank, world, port, V, frames, errs):
                 off += b - a
             seen += off
         assert seen == want.shape[0] and torch.equal(got, want), "rank %d chunked gather mismatch" % rank
+        # ... and its point-to-point counterpart (one asynchronous all-to-all per frame range): interchangeable
+        for chunks in (1, 2, 3):
+            got = torch.full_like(want, float("nan"))
+            seen = 0
+            for ranges, maps in ex.exchange_sources_chunked(own, chunks):
+                off = 0
+                for a, b in ranges:
+                    got[a:b] = maps[off:off + (b - a)]
+                    off += b - a
+                seen += off
+            assert seen == want.shape[0] and torch.equal(got, want), "rank %d chunked p2p exchange mismatch (%d chunks)" % (rank, chunks)
         # projection matrices follow the same pairing: the source matrix of (frame, v) is the
         # reference matrix of camera (v+1) % V of the same frame
         allref = [torch.empty_like(P_ref) for _ in ex.group_ranks]
@@ -78,7 +89,9 @@ def _worker(rank, world, port, V, frames, errs):
         raise
 
 
-@pytest.mark.parametrize("world,V", [(2, 4), (4, 4), (2, 8)])
+# (8, 4): two ranks per camera -- two frame slices, each a group of four ranks of its own (dist.new_group), BASELINE
+# configs[3] on an 8-GPU node
+@pytest.mark.parametrize("world,V", [(2, 4), (4, 4), (2, 8), (8, 4)])
 def test_view_sharded_exchange_gloo(world, V):
     ctx = mp.get_context("spawn")
     errs = ctx.SimpleQueue()
