@@ -32,11 +32,12 @@ ET_VARIANT_TILE_CLASSIC = 65536
 ET_VARIANT_WS_SETPRIO = 262144
 ET_VARIANT_TILE_EXACT = 524288
 ET_VARIANT_WS_BAND = 1048576
-ET_ABI_VERSION = 11
+ET_ABI_VERSION = 12
 ET_GENERAL_POOLING = 1
 ET_GENERAL_PRIOR_MUL = 2
 ET_GENERAL_COSINE = 4
 ET_GENERAL_ATTENTION_MAX = 8
+ET_GENERAL_SIM_PRIOR = 16
 
 
 class EpipolarAmdError(RuntimeError):
@@ -66,7 +67,7 @@ _SIGNATURES = {
     "et_sample_locs": (ctypes.c_int, [_D, _P, _P, _P, _P, _P, _P]),
     "et_epipolar_forward": (ctypes.c_int, [_D, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "et_epipolar_forward_general": (ctypes.c_int, [_D] + [_P] * 8 + [ctypes.c_int32] * 3 + [_P] * 4),
-    "et_epipolar_backward_general": (ctypes.c_int, [_D] + [_P] * 8 + [ctypes.c_int32] * 3 + [_P] * 4),
+    "et_epipolar_backward_general": (ctypes.c_int, [_D] + [_P] * 9 + [ctypes.c_int32] * 3 + [_P] * 5),
     "et_epipolar_forward_workspace_bytes": (ctypes.c_size_t, [_D]),
     "et_epipolar_forward_workspace_stats_offset": (ctypes.c_size_t, [_D]),
     "et_epipolar_forward_workspace_error_offset": (ctypes.c_size_t, [_D]),

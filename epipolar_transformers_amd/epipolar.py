@@ -8,12 +8,14 @@ the K x C x H x W intermediates are replaced by one fused HIP kernel
 The mode every headline config runs -- ATTENTION avg, SIMILARITY dot, soft-max on or off,
 optional 'z' (+BN, +ZRESIDUAL), either normalize convention -- takes the fused HIP kernels.  The operator's
 other branches (theta/phi/g bottleneck, POOLING, ATTENTION max, cosine similarity,
-PRIOR / PRIORMUL, FIND_CORR rgb -- e.g. configs/epipolar/keypoint_h36m_param.yaml) run through ONE general HIP kernel
-over three tensors (`_attend_general_hip` -> et_epipolar_forward_general; HIP backward for the dot-product branches
-without a prior).  What is left to a torch restatement of the reference's op sequence (`_attend_general_chunk`, chunked
-over pairs): SIMILARITY prior, and the prior / cosine / ATTENTION max branches WHEN A GRADIENT IS REQUESTED -- about 5x
-slower than the kernel; the first such call of a process says so in a warning (`EpipolarSlowPathWarning`).
-The reprojection loss and an externally supplied depth raise NotImplementedError.
+PRIOR / PRIORMUL, SIMILARITY prior, FIND_CORR rgb -- e.g. configs/epipolar/keypoint_h36m_param.yaml) run through ONE
+general HIP kernel over three tensors (`_attend_general_hip` -> et_epipolar_forward_general) with a HIP backward for every
+one of them since ABI 12 (et_epipolar_backward_general: cosine, ATTENTION max, both priors incl. the prior tables' own
+gradient).  The torch restatement of the reference's op sequence (`_attend_general_chunk`, chunked over pairs) is what the
+tests compare the kernels with; the module only takes it (with an `EpipolarSlowPathWarning`) for shapes outside the
+kernel's limits (`_general_kernel_applies`) -- no shipped YAML reaches it.
+The reprojection loss and an externally supplied depth raise NotImplementedError (dead for PoseResNet, SURVEY.md a12:
+its caller unpacks four values, resnet.py:385-387).
 """
 from __future__ import annotations
 
@@ -49,7 +51,7 @@ def _warn_slow_path(cfg):
     e = cfg.EPIPOLAR
     warnings.warn("Epipolar: this configuration (ATTENTION %s, SIMILARITY %s, PRIOR %s, POOLING %s, gradients %s) runs the "
                   "chunked torch restatement of the reference's op sequence, not a HIP kernel -- about 5x slower than the "
-                  "general kernel the same configuration takes under torch.no_grad()" %
+                  "general kernel (shape outside its limits, or EPIPOLAR_AMD.GENERAL_KERNEL False)" %
                   (e.ATTENTION, e.SIMILARITY, e.PRIOR, e.POOLING, torch.is_grad_enabled()), EpipolarSlowPathWarning,
                   stacklevel=3)
 
@@ -150,13 +152,18 @@ class Epipolar(nn.Module):
         return tuple(torch.cat([p[i] for p in parts]) for i in range(3))
 
     def _general_kernel_applies(self, feat1, feat2, ref1=None, ref2=None, camera=_ANY, other_camera=_ANY) -> bool:
-        """True when the HIP general kernels compute this call.  Forward (`et_epipolar_forward_general`): every branch of
-        a12 / N4 -- theta / phi / g, BOTTLENECK, POOLING, PRIOR / PRIORMUL, SIMILARITY cos, ATTENTION max, FIND_CORR rgb --
-        except SIMILARITY prior.  With a gradient requested (`et_epipolar_backward_general`, through ops.GeneralAttend):
-        the dot-product branches without a prior; the others then take the chunked torch restatement below."""
+        """True when the HIP general kernels compute this call: every branch of a12 / N4 -- theta / phi / g, BOTTLENECK,
+        POOLING, PRIOR / PRIORMUL, SIMILARITY cos / prior, ATTENTION max, FIND_CORR rgb --, forward
+        (`et_epipolar_forward_general`) and, since ABI 12, backward (`et_epipolar_backward_general`, through
+        ops.GeneralAttend) incl. the prior tables' own gradient.  What is left for the chunked torch restatement below:
+        EPIPOLAR_AMD.GENERAL_KERNEL False, CPU tensors, more than 512 similarity channels, an odd K with POOLING, prior
+        tables whose row count is not K' -- and calls that are ill-formed in the reference too (PRIOR without camera ids,
+        SIMILARITY prior without PRIOR), which fail there with the reference's own error."""
         e = self.cfg.EPIPOLAR
-        if e.ATTENTION not in ("avg", "max") or (e.ATTENTION == "avg" and e.SIMILARITY not in ("dot", "cos")):
+        if e.ATTENTION not in ("avg", "max") or (e.ATTENTION == "avg" and e.SIMILARITY not in ("dot", "cos", "prior")):
             return False
+        if e.ATTENTION == "avg" and e.SIMILARITY == "prior" and not e.PRIOR:
+            return False                               # (epipolar.py:219-224 passes camera ids only with PRIOR: a KeyError there)
         if e.FIND_CORR == "rgb" and (ref1 is None or ref2 is None):
             return False
         if not bool(amd_knob(self.cfg, "GENERAL_KERNEL", True)) or not feat2.is_cuda:
@@ -170,11 +177,6 @@ class Epipolar(nn.Module):
             # own error instead of one from inside ops
             rows = self.sample_size // 2 if e.POOLING else self.sample_size
             if camera is None or other_camera is None or any(t.shape[0] != rows for t in self.prior.values()):
-                return False
-        if (e.PRIOR or e.ATTENTION == "max" or e.SIMILARITY == "cos") and torch.is_grad_enabled():
-            params = [q for k in ("theta", "phi", "g") if k in e.PARAMETERIZED for q in getattr(self, k).parameters()]
-            params += list(self.prior.values()) if e.PRIOR else []
-            if feat1.requires_grad or feat2.requires_grad or any(q.requires_grad for q in params):
                 return False
         c_sim = 3 if e.FIND_CORR == "rgb" else feat1.shape[1] // (e.BOTTLENECK if "theta" in e.PARAMETERIZED else 1)
         return c_sim <= 512
@@ -196,18 +198,17 @@ class Epipolar(nn.Module):
         m2 = self.g(other2) if "g" in e.PARAMETERIZED else other2                       # :152-153
         with torch.no_grad():
             cam = self._cam(P1, P2, feat2.device)
-        is_max, cos = e.ATTENTION == "max", e.ATTENTION == "avg" and e.SIMILARITY == "cos"
-        if not (e.PRIOR or is_max or cos):
-            return ops.GeneralAttend.apply(q, m1, m2, cam, self.layer_spec(), bool(e.POOLING))
-        with torch.no_grad():                                                           # :288-289, :300-301, :308-309
-            prior = None
-            if e.PRIOR and not is_max:
-                prior = torch.stack([self.prior[(int(a), int(b))].to(q) for a, b in zip(camera, other_camera)]).contiguous()
-            out, attn, corr_pos = ops.forward_general_nhwc(self.layer_spec(), ops.to_nhwc(q), ops.to_nhwc(m1), ops.to_nhwc(m2),
-                                                           cam, prior=prior, pooling=bool(e.POOLING),
-                                                           prior_mul=bool(prior is not None and e.PRIORMUL), cosine=cos,
-                                                           attention_max=is_max)
-        return out.permute(0, 3, 1, 2), attn, corr_pos
+        is_max = e.ATTENTION == "max"
+        cos = e.ATTENTION == "avg" and e.SIMILARITY == "cos"
+        sim_prior = e.ATTENTION == "avg" and e.SIMILARITY == "prior"
+        prior = None
+        if e.PRIOR and not is_max:                                                      # :288-289, :300-301, :308-309
+            # the pairs' (camera, other camera) tables, stacked WITH autograd: the kernel returns d(stack), torch adds the
+            # pairs of one camera pair into the table's .grad
+            prior = torch.stack([self.prior[(int(a), int(b))].to(q) for a, b in zip(camera, other_camera)])
+        mode = dict(prior_mul=bool(prior is not None and e.PRIORMUL and not sim_prior), cosine=cos, attention_max=is_max,
+                    sim_prior=sim_prior)
+        return ops.GeneralAttend.apply(q, m1, m2, cam, self.layer_spec(), bool(e.POOLING), prior, mode)
 
     def _attend_general_chunk(self, feat1, feat2, P1, P2, camera=None, other_camera=None, ref1=None, ref2=None):
         """The operator's non-headline branches, restated op for op from epipolar.py:131-247 and

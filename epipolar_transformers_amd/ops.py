@@ -134,9 +134,15 @@ def sample_locs(spec: LayerSpec, cam: torch.Tensor) -> torch.Tensor:
     return out
 
 
+def _general_flags(pooling=False, prior_mul=False, cosine=False, attention_max=False, sim_prior=False) -> int:
+    return ((_lib.ET_GENERAL_POOLING if pooling else 0) | (_lib.ET_GENERAL_PRIOR_MUL if prior_mul else 0) |
+            (_lib.ET_GENERAL_COSINE if cosine else 0) | (_lib.ET_GENERAL_ATTENTION_MAX if attention_max else 0) |
+            (_lib.ET_GENERAL_SIM_PRIOR if sim_prior else 0))
+
+
 def forward_general_nhwc(spec: LayerSpec, q: torch.Tensor, map_sim: torch.Tensor, map_val: torch.Tensor, cam: torch.Tensor,
                          prior: torch.Tensor = None, pooling=False, prior_mul=False, cosine=False, attention_max=False,
-                         want_attn=True, want_corr=True):
+                         want_attn=True, want_corr=True, sim_prior=False):
     """The operator's parameterised / pooled / prior branches as ONE kernel (et_epipolar_forward_general; forward only).
     q, map_sim: (N,H,W,Cs); map_val: (N,H,W,Cv), channels last, contiguous; prior: (N,K',H,W) or None, K' = K/2 with
     `pooling` (epipolar.py:200-202), else K.  Returns out (N,H,W,Cv), attn (N,K',H,W)|None, corr_pos (N,H,W,2)|None."""
@@ -160,8 +166,7 @@ def forward_general_nhwc(spec: LayerSpec, q: torch.Tensor, map_sim: torch.Tensor
     out = _empty((n, h, w, cv), device=q.device)
     attn = _empty((n, ks, h, w), device=q.device) if want_attn else None
     corr = _empty((n, h, w, 2), device=q.device) if want_corr else None
-    flags = ((_lib.ET_GENERAL_POOLING if pooling else 0) | (_lib.ET_GENERAL_PRIOR_MUL if prior_mul else 0) |
-             (_lib.ET_GENERAL_COSINE if cosine else 0) | (_lib.ET_GENERAL_ATTENTION_MAX if attention_max else 0))
+    flags = _general_flags(pooling, prior_mul, cosine, attention_max, sim_prior)
     d = spec.desc(n, 4)
     with torch.cuda.device(q.device):
         _lib.check(_lib.load().et_epipolar_forward_general(
@@ -171,9 +176,11 @@ def forward_general_nhwc(spec: LayerSpec, q: torch.Tensor, map_sim: torch.Tensor
     return out, attn, corr
 
 
-def backward_general_nhwc(spec: LayerSpec, q, map_sim, map_val, cam, grad_out, pooling=False, need_sim=True, need_val=True):
-    """Backward of forward_general_nhwc (no prior): returns (grad_q, grad_map_sim | None, grad_map_val | None), NHWC.
-    The map gradients are accumulated with float atomics (reproducible to rounding only)."""
+def backward_general_nhwc(spec: LayerSpec, q, map_sim, map_val, cam, grad_out, pooling=False, need_sim=True, need_val=True,
+                          prior=None, prior_mul=False, cosine=False, attention_max=False, sim_prior=False, need_prior=False):
+    """Backward of forward_general_nhwc, every branch: returns (grad_q, grad_map_sim | None, grad_map_val | None,
+    grad_prior | None), NHWC maps, grad_prior (N,K',H,W).  The map gradients are accumulated with float atomics
+    (reproducible to rounding only)."""
     for t, nm in ((q, "q"), (map_sim, "map_sim"), (map_val, "map_val"), (cam, "cam"), (grad_out, "grad_out")):
         _require_gpu(t, nm)
     n, h, w, cs = q.shape
@@ -182,39 +189,51 @@ def backward_general_nhwc(spec: LayerSpec, q, map_sim, map_val, cam, grad_out, p
         raise ValueError("grad_out must be a contiguous (N,H,W,Cv) tensor")
     if not (q.is_contiguous() and map_sim.is_contiguous() and map_val.is_contiguous()):
         raise ValueError("q / map_sim / map_val must be contiguous (N,H,W,C) tensors")
+    ks = spec.K // 2 if pooling else spec.K
+    if prior is not None:
+        _require_gpu(prior, "prior")
+        if tuple(prior.shape) != (n, ks, h, w) or not prior.is_contiguous():
+            raise ValueError("prior must be (N,K',H,W) = %s, got %s" % ((n, ks, h, w), tuple(prior.shape)))
     xs, ys, steps = spec.constants(q.device)
     gq = _empty(None, like=q)
     gsim = torch.zeros_like(map_sim) if need_sim else None
     gval = torch.zeros_like(map_val) if need_val else None
+    gprior = _empty(None, like=prior) if (need_prior and prior is not None) else None
     d = spec.desc(n, 4)
+    flags = _general_flags(pooling, prior_mul, cosine, attention_max, sim_prior)
     with torch.cuda.device(q.device):
         _lib.check(_lib.load().et_epipolar_backward_general(
             ctypes.byref(d), _ptr(xs), _ptr(ys), _ptr(steps), _ptr(cam), _ptr(q), _ptr(map_sim), _ptr(map_val),
-            _ptr(grad_out), cs, cv, _lib.ET_GENERAL_POOLING if pooling else 0, _ptr(gq), _ptr(gsim), _ptr(gval),
+            _ptr(prior), _ptr(grad_out), cs, cv, flags, _ptr(gq), _ptr(gsim), _ptr(gval), _ptr(gprior),
             _stream(q)), "et_epipolar_backward_general")
-    return gq, gsim, gval
+    return gq, gsim, gval, gprior
 
 
 class GeneralAttend(torch.autograd.Function):
-    """The parameterised / pooled branches (no prior) with autograd: logical NCHW in and out, `attn` and `corr_pos`
-    without gradient (as EpipolarAttend)."""
+    """The operator's non-headline branches with autograd (every one since ABI 12): logical NCHW in and out, `prior` the
+    (N,K',H,W) stack of the pairs' prior tables or None; `attn` and `corr_pos` without gradient (as EpipolarAttend).
+    `mode`: dict(pooling, prior_mul, cosine, attention_max, sim_prior) of bools."""
 
     @staticmethod
-    def forward(ctx, q, map_sim, map_val, cam, spec: LayerSpec, pooling: bool):
+    def forward(ctx, q, map_sim, map_val, cam, spec: LayerSpec, pooling, prior=None, mode=None):
+        mode = dict(mode or {}, pooling=bool(pooling))
         qn, m1, m2 = to_nhwc(q), to_nhwc(map_sim), to_nhwc(map_val)
-        out, attn, corr = forward_general_nhwc(spec, qn, m1, m2, cam, pooling=pooling)
-        ctx.spec, ctx.pooling = spec, pooling
-        ctx.save_for_backward(qn, m1, m2, cam)
+        pr = None if prior is None else prior.contiguous()
+        out, attn, corr = forward_general_nhwc(spec, qn, m1, m2, cam, prior=pr, **mode)
+        ctx.spec, ctx.mode, ctx.has_prior = spec, mode, pr is not None
+        ctx.save_for_backward(*((qn, m1, m2, cam) + ((pr,) if pr is not None else ())))
         ctx.mark_non_differentiable(attn, corr)
         return out.permute(0, 3, 1, 2), attn, corr
 
     @staticmethod
     def backward(ctx, grad_out, _ga, _gc):
-        qn, m1, m2, cam = ctx.saved_tensors
-        gq, gs, gv = backward_general_nhwc(ctx.spec, qn, m1, m2, cam, to_nhwc(grad_out), ctx.pooling,
-                                           need_sim=ctx.needs_input_grad[1], need_val=ctx.needs_input_grad[2])
+        qn, m1, m2, cam = ctx.saved_tensors[:4]
+        pr = ctx.saved_tensors[4] if ctx.has_prior else None
+        gq, gs, gv, gp = backward_general_nhwc(ctx.spec, qn, m1, m2, cam, to_nhwc(grad_out), need_sim=ctx.needs_input_grad[1],
+                                               need_val=ctx.needs_input_grad[2], prior=pr,
+                                               need_prior=ctx.has_prior and ctx.needs_input_grad[6], **ctx.mode)
         nchw = lambda t: None if t is None else t.permute(0, 3, 1, 2)
-        return nchw(gq) if ctx.needs_input_grad[0] else None, nchw(gs), nchw(gv), None, None, None
+        return nchw(gq) if ctx.needs_input_grad[0] else None, nchw(gs), nchw(gv), None, None, None, gp, None
 
 
 _TILE_BITS = (_lib.ET_VARIANT_TILE_SPLIT | _lib.ET_VARIANT_TILE_CLASSIC |

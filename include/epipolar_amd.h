@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define ET_ABI_VERSION 11
+#define ET_ABI_VERSION 12
 
 /* Static description of one layer call: the cfg keys the reference reads in
  * Epipolar.__init__ (epipolar.py:12-54) and at call time (epipolar.py:303-311,
@@ -175,29 +175,34 @@ int et_epipolar_forward_tiled(const EtLayerDesc *desc, const float *xs, const fl
  *   out      : (N,H,W,c_val)  sum_k' attn_k' * (pooled) sample_k' of map_val   (epipolar.py:243)
  *   attn     nullable : (N,K',H,W);  corr_pos nullable : (N,H,W,2), the location of sample arg-max_k' attn of the
  *              unpooled list (epipolar.py:237-242).
- * ATTENTION avg | max, SIMILARITY dot | cos; FIND_CORR rgb is q = ref1, map_sim = ref2 (3 channels); soft-max on or off
+ * ATTENTION avg | max, SIMILARITY dot | cos | prior; FIND_CORR rgb is q = ref1, map_sim = ref2 (3 channels); soft-max on or off
  * as `desc` says; desc->C is ignored
  * (c_sim <= 512, c_val <= 4096, any positive value).  Nothing of size K x C x H x W is materialised. */
 #define ET_GENERAL_POOLING 1
 #define ET_GENERAL_PRIOR_MUL 2
 #define ET_GENERAL_COSINE 4          /* SIMILARITY cos: F.cosine_similarity(q, sample) (epipolar.py:290-293), then mask / prior / soft-max as for dot */
 #define ET_GENERAL_ATTENTION_MAX 8   /* ATTENTION max (epipolar.py:282-286, 222-235): attn = the raw cosine similarity, out = the arg-max sample of map_val; no prior */
+#define ET_GENERAL_SIM_PRIOR 16      /* SIMILARITY prior (epipolar.py:288-289): attn = the prior table as it is (no similarity, mask or soft-max; q / map_sim are not read); excludes PRIOR_MUL / COSINE / ATTENTION_MAX */
 int et_epipolar_forward_general(const EtLayerDesc *desc, const float *xs, const float *ys, const float *steps,
                                 const float *cam, const float *q, const float *map_sim, const float *map_val,
                                 const float *prior, int c_sim, int c_val, int flags, float *out, float *attn,
                                 float *corr_pos, void *stream);
 
-/* Backward of et_epipolar_forward_general w.r.t. its three tensors, for the branches without a prior (flags:
- * ET_GENERAL_POOLING only):  grad_out (N,H,W,c_val)  ->  grad_q (N,H,W,c_sim), written;  grad_map_sim (N,H,W,c_sim) and
- * grad_map_val (N,H,W,c_val), each nullable (OTHER_GRAD without 'other1' / 'other2', epipolar.py:138-150) and
- * ACCUMULATED with float atomics -- the caller zeroes them first; sums over pixels arrive in any order, so the result
- * is reproducible to rounding only.  The similarities and the soft-max are recomputed from the inputs; the gradient of
- * POOLING's per-channel maximum goes to the sample that won (the first on a tie, as torch.max).  Gradients through the
- * `attn` / `corr_pos` outputs are not provided (the reference configurations never use them). */
+/* Backward of et_epipolar_forward_general w.r.t. its three tensors and the prior, for every branch (same `flags` as
+ * the forward; ABI 12 -- ABI 11 covered the dot-product branches without a prior only):  grad_out (N,H,W,c_val)  ->
+ * grad_q (N,H,W,c_sim), written;  grad_map_sim (N,H,W,c_sim) and grad_map_val (N,H,W,c_val), each nullable (OTHER_GRAD
+ * without 'other1' / 'other2', epipolar.py:138-150) and ACCUMULATED with float atomics -- the caller zeroes them first;
+ * sums over pixels arrive in any order, so the result is reproducible to rounding only;  grad_prior nullable:
+ * (N,K',H,W), written -- the gradient of every pair's prior rows (the caller sums the pairs of one camera pair into the
+ * (camera, other camera) table, epipolar.py:73-80).  The similarities and the soft-max are recomputed from the inputs;
+ * the gradient of POOLING's per-channel maximum goes to the sample that won (the first on a tie, as torch.max); cosine
+ * similarity is differentiated as torch does (through the unclamped norms); ATTENTION max passes grad_out to the first
+ * arg-max sample of map_val only (grad_q = 0, nothing into map_sim); SIMILARITY prior: grad_prior_k' = grad_out . V_k'.
+ * Gradients through the `attn` / `corr_pos` outputs are not provided (the reference configurations never use them). */
 int et_epipolar_backward_general(const EtLayerDesc *desc, const float *xs, const float *ys, const float *steps,
                                  const float *cam, const float *q, const float *map_sim, const float *map_val,
-                                 const float *grad_out, int c_sim, int c_val, int flags, float *grad_q,
-                                 float *grad_map_sim, float *grad_map_val, void *stream);
+                                 const float *prior, const float *grad_out, int c_sim, int c_val, int flags, float *grad_q,
+                                 float *grad_map_sim, float *grad_map_val, float *grad_prior, void *stream);
 
 /* Backward of et_epipolar_forward w.r.t. both feature maps (sample locations
  * carry no gradient, epipolar.py:178-183).  Everything is recomputed from the
