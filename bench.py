@@ -180,13 +180,17 @@ def main():
         out, attn, corr, base = ops.forward_nhwc(spec, ref_c, src_c, cam_c, res_bias=b_fold, want_res_base=True)
         return torch.addmm(base.view(-1, C), out.view(-1, C), w_fold_t, out=base.view(-1, C)), attn, corr
 
+    last_ranges = []                      # (view partition: the pair ranges of the chunks of the most recent step)
+
     def layer_step_view_sharded():
+        del last_ranges[:]
         """North-star partition: the source maps arrive by RCCL all-gather in frame ranges; the fused kernel of
         range i runs while ranges i+1.. are still on the xGMI links."""
         cam = camera.pair_algebra(P_ref_pin, P_src_pin).pin_memory().to(dev, non_blocking=True)
         xs = []
         chunks = (exchange.exchange_sources_chunked if args.p2p else exchange.gather_sources_chunked)(feat_own, args.exchange_chunks)
         for ranges, src_chunk in chunks:
+            last_ranges.append(ranges)
             # contiguous frame ranges: views of the reference maps / camera algebra, no index gather in the timed step
             if len(ranges) == 1:
                 ref_c, cam_c = feat_ref[ranges[0][0]:ranges[0][1]], cam[ranges[0][0]:ranges[0][1]]
@@ -288,6 +292,22 @@ def main():
         elapsed = float(t.item())
     ms_per_step = elapsed / args.steps * 1e3
     value = n_pairs * world * args.steps / elapsed
+    if os.environ.get("BENCH_DUMP_DIR"):
+        # test hook (tests/test_gpu_rccl.py): this rank's inputs and the x of one more step, in the rank's pair order
+        res = layer_step()
+        if exchange is not None:
+            x_all = torch.empty(n_pairs, H, W, C, device=dev)
+            for ranges, xc in zip(last_ranges, res):
+                off = 0
+                for a, b in ranges:
+                    x_all[a:b] = xc.view(-1, H, W, C)[off:off + (b - a)]
+                    off += b - a
+        else:
+            x_all = res[0].view(n_pairs, H, W, C)
+        torch.cuda.synchronize()
+        torch.save({"x": x_all.cpu(), "feat": feat_own.cpu(), "P_ref": P_ref, "P_src": P_src, "w_fold_t": w_fold_t.cpu(),
+                    "b_fold": b_fold.cpu(), "my_cams": None if exchange is None else exchange.my_cams},
+                   os.path.join(os.environ["BENCH_DUMP_DIR"], "rank%d.pt" % rank))
 
     # ---- roofline of the dominant kernel: HIP events on the launch stream -----------------
     cam = camera.pair_algebra(P_ref, P_src).to(dev)
@@ -723,6 +743,32 @@ def cpu_baseline(args, spec, feat_ref, feat_src, P_ref, P_src, gpu_same_scope):
                      "threads), fused sample+attention only (no z/BN), the reference's per-pair op sequence "
                      "(oracle/torch_ref_path.py) in PyTorch CPU"
                      % (n_t, feat_ref.shape[0], best_t, n_s, "/".join(str(c) for c in counts))}
+    # --- the REAL reference, where its tree exists (EPIPOLAR_REFERENCE_ROOT, default /root/reference: the build container; never
+    # the GPU box): Epipolar.forward itself, eval mode, no_grad, the z branch switched off (same scope as above), on the same
+    # sample at the same thread count.  Then THIS is the cpu_baseline (kind "reference") and the op-sequence port moves beside it.
+    from oracle import ref_harness as rh
+    if rh.reference_available():
+        try:
+            mod, rcfg = rh.reference_epipolar(overrides=["KEYPOINT.HEATMAP_SIZE", "(%d, %d)" % (spec.H, spec.W), "KEYPOINT.NFEATS",
+                                                        str(feat_ref.shape[-1]), "EPIPOLAR.SAMPLESIZE", str(spec.K),
+                                                        "DATASETS.IMAGE_SIZE", "(%d, %d)" % (4 * spec.H, 4 * spec.W),
+                                                        "EPIPOLAR.PARAMETERIZED", "()"])
+            mod.eval()
+            torch.set_num_threads(best_t)
+            t1, t2 = torch.from_numpy(f1), torch.from_numpy(f2)
+            with torch.no_grad():
+                mod(t1[:1], t2[:1], P_ref[:1], P_src[:1])                       # warm-up
+                t0 = time.perf_counter()
+                mod(t1, t2, P_ref[:n_t], P_src[:n_t])
+                dt_r = time.perf_counter() - t0
+            real = dict(ref, value=n_t / dt_r, kind="reference",
+                        implementation="the reference itself: %s modeling/layers/epipolar.py Epipolar.forward (eval, no_grad, z off)" % rh.REFERENCE_ROOT,
+                        sample="%d of the %d pairs of one GPU's batch through the reference's own Epipolar.forward at %d threads, "
+                               "fused sample+attention scope (PARAMETERIZED ())" % (n_t, feat_ref.shape[0], best_t))
+            real["op_sequence_port_value"] = ref["value"]
+            ref = real
+        except Exception as exc:      # (a reference tree that does not import here: keep the port, say why)
+            ref["reference_unavailable"] = repr(exc)[:200]
     # --- the C port
     n = min(args.cpu_pairs, feat_ref.shape[0])
     f1 = feat_ref[:n].permute(0, 3, 1, 2).contiguous().cpu().numpy()

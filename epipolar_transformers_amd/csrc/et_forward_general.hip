@@ -374,6 +374,7 @@ __global__ __launch_bounds__(kWave *kGenWaves) void epipolar_bwd_general_kernel(
             sim[s] = p.cosine ? raw / (nq * np_[s]) : raw;           // (the forward's expression)
             da[s] = in ? s_a[k] : 0.f;
             pr[s] = (in && p.prior) ? p.prior[((size_t)n * Ks + k) * HW + pix] : 0.f;
+            if (p.sim_prior) sim[s] = pr[s];
             aout[s] = alpha[s] = beta[s] = dprior[s] = 0.f;
         }
         if (p.attn_max) {
@@ -528,8 +529,8 @@ int check_sim_prior(const char *who, int flags, bool has_prior)
 {
     if (!(flags & ET_GENERAL_SIM_PRIOR)) return 0;
     if (!has_prior) return fail("%s: SIM_PRIOR without a prior", who);
-    if (flags & (ET_GENERAL_PRIOR_MUL | ET_GENERAL_COSINE | ET_GENERAL_ATTENTION_MAX))
-        return fail("%s: SIM_PRIOR excludes PRIOR_MUL / COSINE / ATTENTION_MAX (flags=%d)", who, flags);
+    if (flags & (ET_GENERAL_PRIOR_MUL | ET_GENERAL_COSINE))
+        return fail("%s: SIM_PRIOR excludes PRIOR_MUL / COSINE (flags=%d)", who, flags);
     return 0;
 }
 }  // namespace
@@ -551,7 +552,8 @@ int et_epipolar_forward_general(const EtLayerDesc *desc, const float *xs, const 
     if (c_val <= 0 || c_val > 4096) return fail("et_epipolar_forward_general: c_val=%d outside [1, 4096]", c_val);
     if (flags & ~(ET_GENERAL_POOLING | ET_GENERAL_PRIOR_MUL | ET_GENERAL_COSINE | ET_GENERAL_ATTENTION_MAX | ET_GENERAL_SIM_PRIOR))
         return fail("et_epipolar_forward_general: unknown flag bits %d", flags);
-    if ((flags & ET_GENERAL_ATTENTION_MAX) && prior) return fail("et_epipolar_forward_general: ATTENTION max takes no prior");
+    if ((flags & ET_GENERAL_ATTENTION_MAX) && prior && !(flags & ET_GENERAL_SIM_PRIOR))
+        return fail("et_epipolar_forward_general: ATTENTION max takes no prior");
     if (int e = check_sim_prior("et_epipolar_forward_general", flags, prior != nullptr)) return e;
     const bool pool = flags & ET_GENERAL_POOLING;
     if (pool && (desc->K & 1)) return fail("et_epipolar_forward_general: POOLING needs an even K (K=%d)", desc->K);
@@ -591,7 +593,8 @@ int et_epipolar_backward_general(const EtLayerDesc *desc, const float *xs, const
     if (c_val <= 0 || c_val > 4096) return fail("et_epipolar_backward_general: c_val=%d outside [1, 4096]", c_val);
     if (flags & ~(ET_GENERAL_POOLING | ET_GENERAL_PRIOR_MUL | ET_GENERAL_COSINE | ET_GENERAL_ATTENTION_MAX | ET_GENERAL_SIM_PRIOR))
         return fail("et_epipolar_backward_general: unknown flag bits %d", flags);
-    if ((flags & ET_GENERAL_ATTENTION_MAX) && prior) return fail("et_epipolar_backward_general: ATTENTION max takes no prior");
+    if ((flags & ET_GENERAL_ATTENTION_MAX) && prior && !(flags & ET_GENERAL_SIM_PRIOR))
+        return fail("et_epipolar_backward_general: ATTENTION max takes no prior");
     if ((flags & ET_GENERAL_PRIOR_MUL) && !prior) return fail("et_epipolar_backward_general: PRIOR_MUL without a prior");
     if (int e = check_sim_prior("et_epipolar_backward_general", flags, prior != nullptr)) return e;
     if (grad_prior && !prior) return fail("et_epipolar_backward_general: grad_prior without a prior");

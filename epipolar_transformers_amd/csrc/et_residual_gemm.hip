@@ -41,4 +41,38 @@ int et_residual_gemm(int64_t num_pixels, int32_t C, const float *out, const floa
     return check_launch("et_residual_gemm");
 }
 
+size_t et_z_batch_stats_workspace_bytes(int64_t num_pixels)
+{
+    if (num_pixels <= 0) return 0;
+    return (size_t)((num_pixels + kRgRows - 1) / kRgRows) * 512 * sizeof(float);
+}
+
+// First pass of the training-mode epilogue: y = out . Wz^T + bz (written: the batch norm's input) and its per-channel batch
+// mean / biased variance over all num_pixels rows (BN.py:59-82 with training = True).  `packed_wz`: et_residual_gemm_pack of the
+// raw 256 x 256 z weight.
+int et_z_batch_stats(int64_t num_pixels, int32_t C, const float *out, const void *packed_wz, const float *z_bias, float *y,
+                     float *mean, float *var, void *workspace, size_t workspace_bytes, void *stream)
+{
+    if (C != 256) return fail("et_z_batch_stats: C = %d (the kernel is written for the 256-channel head)", C);
+    if (num_pixels <= 1) return fail("et_z_batch_stats: batch statistics need more than one row (got %lld)", (long long)num_pixels);
+    if (!out || !packed_wz || !z_bias || !y || !mean || !var || !workspace) return fail("et_z_batch_stats: NULL pointer");
+    if (reinterpret_cast<uintptr_t>(packed_wz) & 15) return fail("et_z_batch_stats: packed buffer must be 16-byte aligned");
+    if (workspace_bytes < et_z_batch_stats_workspace_bytes(num_pixels))
+        return fail("et_z_batch_stats: workspace of %zu bytes is smaller than the %zu required", workspace_bytes,
+                    et_z_batch_stats_workspace_bytes(num_pixels));
+    const long long blocks = (num_pixels + kRgRows - 1) / kRgRows;
+    if (blocks > 0x7fffffffLL) return fail("et_z_batch_stats: too many rows");
+    hipStream_t st = (hipStream_t)stream;
+    const int dev = current_device();
+    auto kern = residual_gemm_kernel<false, true>;
+    ET_GRANT_LDS(kern, kRgLdsBytes, dev);
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), kRgLdsBytes, st, out, (const float *)nullptr,
+                       reinterpret_cast<const unsigned *>(packed_wz), z_bias, y, (long long)num_pixels,
+                       reinterpret_cast<float *>(workspace));
+    if (int e = check_launch("et_z_batch_stats(gemm)")) return e;
+    hipLaunchKernelGGL(z_stats_finish_kernel, dim3(256), dim3(256), 0, st, reinterpret_cast<const float *>(workspace), blocks,
+                       (long long)num_pixels, z_bias, mean, var);
+    return check_launch("et_z_batch_stats(finish)");
+}
+
 }  // extern "C"

@@ -67,6 +67,49 @@ class zeroinitBN(nn.BatchNorm2d):
             nn.init.zeros_(self.bias)
 
 
+class _TrainEpilogue(torch.autograd.Function):
+    """bn(z(out)) [+ out] [+ feat] with BATCH statistics (epipolar.py:250-253, BN.py:59-82 with training = True, resnet.py:388)
+    for the 256-channel head as two passes of the hand-written GEMM kernel instead of five stock ops:
+      1. `ops.z_batch_stats`: y = z(out) (kept: the batch norm's input, as autograd keeps it in the reference) and its per-channel
+         batch mean / variance (per-block centred sums merged pairwise in double: no cancellation, no atomics);
+      2. `ops.residual_gemm` with the statistics folded into the weight: Wf = diag(gamma / sigma) Wz [+ I],
+         bias = (bz - mean) gamma / sigma + beta -- the same kernel the eval path runs.
+    Backward: the library kernels autograd itself would call for these ops (aten's batch-norm and convolution backward) on the
+    saved y / out, so the gradients are the stock ones."""
+
+    @staticmethod
+    def forward(ctx, out, feat, zw, zb, gamma, beta, eps, zresidual):
+        o = ops.to_nhwc(out)
+        c = o.shape[-1]
+        w2 = zw.detach().reshape(c, c)
+        y, mean, var = ops.z_batch_stats(o, ops.residual_gemm_pack(w2), zb.detach().contiguous())
+        invstd = torch.rsqrt(var + eps)
+        s = gamma.detach() * invstd
+        wf = w2 * s[:, None]
+        if zresidual:
+            wf = wf + torch.eye(c, dtype=wf.dtype, device=wf.device)
+        bf = ((zb.detach() - mean) * s + beta.detach()).contiguous()
+        x = ops.residual_gemm(o, ops.residual_gemm_pack(wf.contiguous()), bf, None if feat is None else ops.to_nhwc(feat))
+        ctx.save_for_backward(o, y, zw, gamma, mean, invstd)
+        ctx.eps, ctx.zresidual, ctx.has_feat = eps, zresidual, feat is not None
+        ctx.mark_non_differentiable(mean, var)
+        return x.permute(0, 3, 1, 2), mean, var
+
+    @staticmethod
+    def backward(ctx, gx, _gm, _gv):
+        o, y, zw, gamma, mean, invstd = ctx.saved_tensors
+        g = gx.contiguous(memory_format=torch.channels_last)
+        dy, dgamma, dbeta = torch.ops.aten.native_batch_norm_backward(
+            g, y.permute(0, 3, 1, 2), gamma, None, None, mean, invstd, True, ctx.eps, [True, True, True])
+        dout, dzw, dzb = torch.ops.aten.convolution_backward(
+            dy, o.permute(0, 3, 1, 2), zw, [zw.shape[0]], [1, 1], [0, 0], [1, 1], False, [0, 0], 1,
+            [bool(ctx.needs_input_grad[0]), True, True])
+        if ctx.needs_input_grad[0] and ctx.zresidual:
+            dout = dout + g
+        return (dout if ctx.needs_input_grad[0] else None, g if ctx.has_feat and ctx.needs_input_grad[1] else None,
+                dzw, dzb, dgamma, dbeta, None, None)
+
+
 class Epipolar(nn.Module):
     def __init__(self, debug=False, cfg=None):
         super().__init__()
@@ -118,13 +161,11 @@ class Epipolar(nn.Module):
         e = self.cfg.EPIPOLAR
         assert e.ATTENTION in {"avg", "max"}                 # epipolar.py:107
         assert e.SIMILARITY in {"cos", "dot", "prior"}        # epipolar.py:108
-        unsupported = []
         if e.REPROJECT_LOSS_WEIGHT != 0:
-            unsupported.append("REPROJECT_LOSS_WEIGHT")
-        if depth is not None:
-            unsupported.append("externally supplied depth")
-        if unsupported:
-            raise NotImplementedError("not on the MI355X path: " + ", ".join(unsupported))
+            # epipolar.py:257-261, 420-464: a 5-tuple return PoseResNet cannot unpack (resnet.py:385-387 takes four values) --
+            # dead code for every backbone on the path; INTEGRATION.md "What raises"
+            raise NotImplementedError("not on the MI355X path: REPROJECT_LOSS_WEIGHT != 0 (the reference's reprojection "
+                                      "branch, unreachable through PoseResNet)")
 
     def _fused_mode(self, ref1=None, ref2=None) -> bool:
         """True when the call is the headline mode the fused HIP kernels implement."""
@@ -180,6 +221,26 @@ class Epipolar(nn.Module):
                 return False
         c_sim = 3 if e.FIND_CORR == "rgb" else feat1.shape[1] // (e.BOTTLENECK if "theta" in e.PARAMETERIZED else 1)
         return c_sim <= 512
+
+    def _attend_with_depth(self, feat1, feat2, P1, P2, depth):
+        """An externally supplied `depth` (epipolar.py:101-104, 217-218): the given (N,K',H,W) weights REPLACE the similarity
+        -- no mask, no soft-max --, `out` is their weighted sum of the (pooled) samples of other2 (ATTENTION avg, :243) or the
+        arg-max sample (ATTENTION max, :225-235), and the z branch is skipped (:249).  One launch of the general kernel in its
+        SIM_PRIOR mode (the weights take the prior's place), with the gradient of both the value map and the weights."""
+        e = self.cfg.EPIPOLAR
+        w = depth if torch.is_tensor(depth) else torch.stack(list(depth))
+        rows = self.sample_size // 2 if e.POOLING else self.sample_size
+        if w.dim() != 4 or w.shape[0] != feat2.shape[0] or w.shape[1] != rows or tuple(w.shape[2:]) != (self.feat_h, self.feat_w):
+            raise ValueError("depth must be (N, %d, %d, %d) weights, got %s" % (rows, self.feat_h, self.feat_w, tuple(w.shape)))
+        other2 = feat2 if "other2" in e.OTHER_GRAD else feat2.detach()                  # :147-150
+        m2 = self.g(other2) if "g" in e.PARAMETERIZED else other2                       # :152-153
+        with torch.no_grad():
+            cam = self._cam(P1, P2, feat2.device)
+        unused = feat2.new_zeros((feat2.shape[0], 4, self.feat_h, self.feat_w))        # (q / similarity map: not read in this mode)
+        mode = dict(prior_mul=False, cosine=False, attention_max=e.ATTENTION == "max", sim_prior=True)
+        out, _, corr_pos = ops.GeneralAttend.apply(unused, unused, m2, cam, self.layer_spec(), bool(e.POOLING),
+                                                   w.to(feat2).contiguous(), mode)
+        return out, w, corr_pos
 
     def _attend_general_hip(self, feat1, feat2, P1, P2, camera=None, other_camera=None, ref1=None, ref2=None):
         """The non-headline branches through the HIP general kernels: the 1x1 convolutions act on the maps
@@ -391,8 +452,35 @@ class Epipolar(nn.Module):
             return False
         return not (has_z and self.bn.training)
 
+    def _train_epilogue_applies(self, out) -> bool:
+        """The z branch in TRAINING mode through the hand-written GEMM kernels (`_TrainEpilogue`): the 256-channel head with
+        the layer's own batch norm (a SyncBatchNorm2d spans ranks: its statistics go through an all-reduce, parallel.py)."""
+        return ("z" in self.cfg.EPIPOLAR.PARAMETERIZED and self.bn.training and out.is_cuda and out.dtype == torch.float32 and
+                out.shape[1] == 256 and self.z.in_channels == 256 and self.z.out_channels == 256 and
+                type(self.bn) in (zeroinitBN, nn.BatchNorm2d) and self.bn.affine and out.shape[0] * out.shape[2] * out.shape[3] > 1 and
+                bool(amd_knob(self.cfg, "FUSED_TRAIN_EPILOGUE", True)))
+
+    def _train_epilogue(self, out, feat1=None):
+        bn = self.bn
+        x, mean, var = _TrainEpilogue.apply(out, feat1, self.z.weight, self.z.bias, bn.weight, bn.bias, float(bn.eps),
+                                            bool(self.cfg.EPIPOLAR.ZRESIDUAL))
+        if bn.track_running_stats:                                   # BN.py:59-70: what F.batch_norm does to the buffers
+            with torch.no_grad():
+                bn.num_batches_tracked += 1
+                m = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked)
+                n = out.shape[0] * out.shape[2] * out.shape[3]
+                bn.running_mean.mul_(1 - m).add_(mean, alpha=m)
+                bn.running_var.mul_(1 - m).add_(var * (n / (n - 1.0)), alpha=m)
+        return x
+
     def _epilogue_torch(self, out, feat1=None):
-        """Training path (batch statistics / autograd): the reference's own op sequence."""
+        """Training path (batch statistics / autograd): two passes of the GEMM kernel for the 256-channel head
+        (`_train_epilogue`), otherwise the reference's own op sequence."""
+        if self._train_epilogue_applies(out):
+            if feat1 is None:
+                return self._train_epilogue(out), None
+            # (forward_fused only consumes x = finalout + feat: one kernel adds the feature row as well)
+            return None, self._train_epilogue(out, feat1)
         finalout = out
         if "z" in self.cfg.EPIPOLAR.PARAMETERIZED:
             finalout = self.bn(self.z(out))                                  # epipolar.py:250-251
@@ -405,6 +493,14 @@ class Epipolar(nn.Module):
         feat1, feat2: N x C x H x W ; P1, P2: N x 3 x 4
         returns (finalout, corr_pos[N,H,W,2], depth[N,K,H,W], sample_locs | None)."""
         self._check_mode(depth, ref1, ref2)
+        if depth is not None:
+            out, attn, corr_pos = self._attend_with_depth(feat1, feat2, P1, P2, depth)
+            sample_locs = None
+            if self.debug or self.cfg.VIS.EPIPOLAR_LINE:
+                sample_locs = ops.sample_locs(self.layer_spec(), self._cam(P1, P2, feat2.device))
+            if self.debug:
+                return (out, corr_pos, attn, sample_locs) + self._debug_geometry(self._cam(P1, P2, feat2.device))
+            return out, corr_pos, attn, (sample_locs.transpose(0, 1) if sample_locs is not None else None)
         fused = self._fused_mode(ref1, ref2)
         if fused:
             out, attn, corr_pos = self.attend(feat1, feat2, P1, P2)

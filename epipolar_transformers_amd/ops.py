@@ -543,6 +543,30 @@ def residual_gemm(out: torch.Tensor, packed: torch.Tensor, bias: torch.Tensor, f
     return x
 
 
+def z_batch_stats(out: torch.Tensor, packed_wz: torch.Tensor, z_bias: torch.Tensor):
+    """First pass of the training-mode epilogue (et_z_batch_stats): y = out @ Wz^T + z_bias over the last dimension (256)
+    and its per-channel batch mean / biased variance over all rows.  Returns (y, mean, var)."""
+    _require_gpu(out, "out")
+    c = out.shape[-1]
+    if c != 256 or not out.is_contiguous():
+        raise ValueError("out must be a contiguous (..., 256) tensor")
+    if not (z_bias.is_cuda and z_bias.numel() == c and z_bias.is_contiguous() and z_bias.dtype == torch.float32):
+        raise ValueError("z_bias must be a contiguous float32 vector of 256 values on the GPU")
+    lib = _lib.load()
+    if packed_wz.numel() < int(lib.et_residual_gemm_packed_bytes()) or packed_wz.dtype != torch.uint8 or not packed_wz.is_cuda:
+        raise ValueError("packed_wz must be the buffer residual_gemm_pack returns")
+    rows = out.numel() // c
+    y = _empty(None, like=out)
+    mean = _empty((c,), device=out.device)
+    var = _empty((c,), device=out.device)
+    ws_bytes = int(lib.et_z_batch_stats_workspace_bytes(rows))
+    with torch.cuda.device(out.device):
+        ws = _workspace(out.device, ws_bytes, "zstats")
+        _lib.check(lib.et_z_batch_stats(rows, c, _ptr(out), _ptr(packed_wz), _ptr(z_bias), _ptr(y), _ptr(mean), _ptr(var), _ptr(ws),
+                                        ctypes.c_size_t(ws_bytes), _stream(out)), "et_z_batch_stats")
+    return y, mean, var
+
+
 def heatmap_peaks(heatmaps: torch.Tensor, radius: float, downsample: float, threshold: float = 1e-6,
                   legacy_floor_division: bool = False):
     """find_tensor_peak_batch for a whole batch in ONE kernel: heatmaps (N,J,H,W) -> locations (N,J,2) in image

@@ -182,7 +182,7 @@ int et_epipolar_forward_tiled(const EtLayerDesc *desc, const float *xs, const fl
 #define ET_GENERAL_PRIOR_MUL 2
 #define ET_GENERAL_COSINE 4          /* SIMILARITY cos: F.cosine_similarity(q, sample) (epipolar.py:290-293), then mask / prior / soft-max as for dot */
 #define ET_GENERAL_ATTENTION_MAX 8   /* ATTENTION max (epipolar.py:282-286, 222-235): attn = the raw cosine similarity, out = the arg-max sample of map_val; no prior */
-#define ET_GENERAL_SIM_PRIOR 16      /* SIMILARITY prior (epipolar.py:288-289): attn = the prior table as it is (no similarity, mask or soft-max; q / map_sim are not read); excludes PRIOR_MUL / COSINE / ATTENTION_MAX */
+#define ET_GENERAL_SIM_PRIOR 16      /* SIMILARITY prior (epipolar.py:288-289) and an externally supplied `depth` (:217-218): attn = the given (N,K',H,W) weights as they are (no similarity, mask or soft-max; q / map_sim are not read); excludes PRIOR_MUL / COSINE; with ATTENTION_MAX the output is the arg-max sample of those weights */
 int et_epipolar_forward_general(const EtLayerDesc *desc, const float *xs, const float *ys, const float *steps,
                                 const float *cam, const float *q, const float *map_sim, const float *map_val,
                                 const float *prior, int c_sim, int c_val, int flags, float *out, float *attn,
@@ -266,6 +266,21 @@ size_t et_residual_gemm_packed_bytes(void);
 int et_residual_gemm_pack(const float *wf, void *packed, void *stream);
 int et_residual_gemm(int64_t num_pixels, int32_t C, const float *out, const float *feat, const void *packed,
                      const float *bias, float *x, void *stream);
+
+/* First pass of the layer's TRAINING-mode epilogue (ABI 12): the z branch with BATCH statistics -- bn(z(out)) with
+ * training = True (epipolar.py:250-251, modeling/layers/BN.py:59-82) -- for the 256-channel head:
+ *   y    : (num_pixels, 256) written: out . Wz^T + z_bias, the batch norm's input (what autograd keeps for the backward)
+ *   mean : (256) written: per-channel mean of y over all num_pixels rows
+ *   var  : (256) written: per-channel BIASED variance of y (what the batch norm normalises with; the running estimate
+ *          takes var * n / (n - 1))
+ * `packed_wz` = et_residual_gemm_pack of the raw z weight (256 out x 256 in).  Per 64-row block the kernel keeps a mean and
+ * a centred sum of squares per channel (workspace: et_z_batch_stats_workspace_bytes(num_pixels) bytes, no initialisation
+ * needed), merged pairwise in double precision -- no sum-of-squares cancellation, no float atomics, bit-reproducible.
+ * The second pass is et_residual_gemm with the statistics folded into the weight:
+ *   Wf = diag(gamma / sqrt(var + eps)) Wz [+ I],  bias = (z_bias - mean) gamma / sqrt(var + eps) + beta. */
+size_t et_z_batch_stats_workspace_bytes(int64_t num_pixels);
+int et_z_batch_stats(int64_t num_pixels, int32_t C, const float *out, const void *packed_wz, const float *z_bias, float *y,
+                     float *mean, float *var, void *workspace, size_t workspace_bytes, void *stream);
 
 /* The whole eval-mode layer as ONE data kernel (ABI 11): the sampling + attention of et_epipolar_forward_tiled with
  *     x = feat_ref + bias + out . Wf^T

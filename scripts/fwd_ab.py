@@ -8,14 +8,15 @@ from epipolar_transformers_amd import _lib, camera, ops, synthetic as syn
 
 label = sys.argv[1] if len(sys.argv) > 1 else os.path.basename(os.environ.get("EPIPOLAR_AMD_LIB", "default"))
 dev = torch.device("cuda:0")
-H, C, K = 64, 256, 64
-P1, P2 = syn.make_pairs(32, 4, H * 4, seed=1000, jitter=(0.05, 8.0))
+H, C, K = int(os.environ.get("AB_HW", "64")), 256, int(os.environ.get("AB_K", "64"))      # (Config 5: AB_HW=128 AB_K=128 AB_PAIRS=64 AB_VIEWS=8)
+NP, V = int(os.environ.get("AB_PAIRS", "128")), int(os.environ.get("AB_VIEWS", "4"))
+P1, P2 = syn.make_pairs(NP // V, V, H * 4, seed=1000, jitter=(0.05, 8.0))
 g = torch.Generator(device=dev).manual_seed(0)
-ref = torch.randn(128, H, H, C, device=dev, generator=g).relu_()
-src = torch.randn(128, H, H, C, device=dev, generator=g).relu_()
+ref = torch.randn(NP, H, H, C, device=dev, generator=g).relu_()
+src = torch.randn(NP, H, H, C, device=dev, generator=g).relu_()
 cam = camera.pair_algebra(P1, P2).to(dev)
 spec = ops.LayerSpec(H=H, W=H, K=K, variant=int(os.environ.get("AB_VARIANT", "0")))
-ws = ops.tile_workspace(spec, 128, C, dev)
+ws = ops.tile_workspace(spec, NP, C, dev)
 fused = os.environ.get("AB_FUSED") == "1"
 if fused:
     packed = ops.residual_gemm_pack(torch.randn(C, C, device=dev, generator=g) * 0.05 + torch.eye(C, device=dev))

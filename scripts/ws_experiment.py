@@ -1,7 +1,9 @@
 #!/usr/bin/env python
 """Which role bounds the warp-specialised forward (development tool).  Needs the profiling build
 (`python -m epipolar_transformers_amd.build --profile`, run with EPIPOLAR_AMD_LIB=.../libepipolar_amd_prof.so): its host
-wrapper reads ET_WS_EXPERIMENT per call -- bit 128: no G1, 64: no G2, 32: no S1, 16: no A-stage copy, 8: no SM (results are wrong, timing only)."""
+wrapper reads ET_WS_EXPERIMENT per call -- bit 128: no G1, 64: no G2, 32: no S1, 16: no A-stage copy, 8: no SM (results are wrong, timing only), 2: tiles assigned
+statically (block jx of an XCD takes tiles jx, jx + nbx, ..) instead of drawn from the XCD's counter (results stay right).
+Round 5 used it to settle what the "skeleton" time is: see profiles/r05_ws_role_experiment.txt."""
 import os
 import sys
 
@@ -36,7 +38,10 @@ def events_ms(fn, reps=20, warm=3):
 
 for name, bits in (("everything", 0), ("no G1", 128), ("no G2", 64), ("vector waves only (no G1, no G2)", 192),
                    ("no SM", 8), ("no SM, no G2", 72), ("S1 + S2 + copy only", 200), ("S1 + S2 only", 216), ("copy only", 232),
-                   ("skeleton (barriers, tile walk)", 248), ("no S1 (empty tiles)", 32), ("no copy", 16)):
+                   ("skeleton (barriers, tile walk, operand prefetches)", 248),
+                   ("skeleton, tiles assigned statically (no atomic draw)", 250),
+                   ("everything, tiles assigned statically", 2),
+                   ("no S1 (empty tiles)", 32), ("no copy", 16)):
     os.environ["ET_WS_EXPERIMENT"] = str(bits)
     m, lo = events_ms(lambda: ops.forward_nhwc(spec, ref, src, cam))
     print("%-36s forward call %.3f ms (min %.3f)" % (name, m, lo), flush=True)

@@ -35,6 +35,10 @@ CASES = [
                                                "DATASETS.CAMERAS", "(1, 2, 3, 4)", "EPIPOLAR.PARAMETERIZED", "()"]),
     dict(name="rgb_corr_c8_k8", C=8, K=8, ov=["EPIPOLAR.FIND_CORR", "rgb", "EPIPOLAR.OTHER_GRAD", "('other2',)",
                                               "EPIPOLAR.PARAMETERIZED", "()"]),
+    # an externally supplied `depth` (epipolar.py:101-104, 217-218, 249): the given weights replace the similarity, no z
+    dict(name="depth_given_c8_k8", C=8, K=8, depth=True, ov=["EPIPOLAR.PARAMETERIZED", "('z',)", "EPIPOLAR.ZRESIDUAL", "True"]),
+    dict(name="depth_given_max_c8_k8", C=8, K=8, depth=True, ov=["EPIPOLAR.ATTENTION", "max", "EPIPOLAR.PARAMETERIZED", "('z',)",
+                                                                "EPIPOLAR.ZRESIDUAL", "True"]),
 ]
 
 
@@ -62,6 +66,10 @@ def run_case(c):
     kw = dict(camera=camera, other_camera=other_camera)
     if "rgb" in c["name"]:
         kw.update(ref1=rgb1, ref2=rgb2)
+    given = None
+    if c.get("depth"):
+        given = torch.softmax(2.0 * torch.randn(N, c["K"], H, H, generator=g), 1).requires_grad_(True)
+        kw.update(depth=list(given.unbind(0)))          # (the reference stacks it at the end, epipolar.py:263: a list of (K,H,W))
     mod.eval()
     a1, a2 = f1.clone().requires_grad_(True), f2.clone().requires_grad_(True)
     fin, corr_pos, depth, _ = mod(a1, a2, P1, P2, **kw)
@@ -76,6 +84,9 @@ def run_case(c):
                 grad_feat1=npf(a1.grad) if a1.grad is not None else np.zeros_like(npf(f1)),
                 grad_feat2=npf(a2.grad) if a2.grad is not None else np.zeros_like(npf(f2)),
                 overrides=np.array(c["ov"]), meta=np.array([H, c["C"], c["K"], N, IMAGE], np.int64))
+    if given is not None:
+        data["depth_given"] = npf(given)
+        data["grad_depth"] = npf(given.grad) if given.grad is not None else np.zeros_like(npf(given))
     for k, v in mod.state_dict().items():
         data["sd." + k] = npf(v) if v.dtype.is_floating_point else v.numpy()
     for (i, j), v in getattr(mod, "prior", {}).items():
@@ -88,7 +99,10 @@ def main():
     torch.set_num_threads(4)
     outdir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "modes")
     os.makedirs(outdir, exist_ok=True)
+    only = set(sys.argv[1:])
     for c in CASES:
+        if only and c["name"] not in only:
+            continue
         data = run_case(c)
         path = os.path.join(outdir, c["name"] + ".npz")
         np.savez_compressed(path, **data)

@@ -155,3 +155,85 @@ def test_fused_entry_refuses_shapes_of_the_other_kernels(env):
     with pytest.raises(_lib.EpipolarAmdError):
         ops.forward_fused_nhwc(spec, t, t, torch.zeros(1, 27, device="cuda"), ops.residual_gemm_pack(torch.eye(C, device="cuda")),
                                torch.zeros(C, device="cuda"))
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The TRAINING-mode epilogue through the same GEMM kernel (round 5): et_z_batch_stats + et_residual_gemm with the batch
+# statistics folded into the weight, in place of conv1x1 + batch_norm(training) + two adds as stock torch ops.
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("rows", [64 * 5, 1587, 70000], ids=["5-blocks", "ragged-1587", "70000"])
+def test_z_batch_stats_vs_float64(env, rows):
+    """y, mean and biased variance against float64 -- with one channel that hardly varies around a large mean (0.2 +- 6e-3: the
+    conditioning of the 8-channel fixtures; a sum-of-squares formula loses it) and one that is constant."""
+    _lib, camera, ops = env
+    g = torch.Generator(device="cuda").manual_seed(rows)
+    out = torch.randn(rows, C, device="cuda", generator=g).relu_()
+    wz = torch.randn(C, C, device="cuda", generator=g) * 0.05
+    bz = torch.randn(C, device="cuda", generator=g) * 0.1
+    wz[3] = 0
+    wz[3, :8] = 1e-3            # channel 3: tiny spread ...
+    bz[3] = 0.2                 # ... around 0.2
+    wz[5] = 0                   # channel 5: constant
+    y, mean, var = ops.z_batch_stats(out, ops.residual_gemm_pack(wz), bz)
+    y2, mean2, var2 = ops.z_batch_stats(out, ops.residual_gemm_pack(wz), bz)
+    assert torch.equal(y, y2) and torch.equal(mean, mean2) and torch.equal(var, var2)          # no atomics: bit-reproducible
+    want = out.double() @ wz.double().t() + bz.double()
+    assert (y.double() - want).abs().max().item() <= 4e-6 * max(1.0, want.abs().max().item())
+    wm, wv = want.mean(0), want.var(0, unbiased=False)
+    assert (mean.double() - wm).abs().max().item() <= 2e-6 * max(1.0, wm.abs().max().item())
+    rel = ((var.double() - wv).abs() / wv.clamp_min(1e-30))
+    rel[5] = 0
+    assert rel.max().item() <= 1e-4, (rel.max().item(), int(rel.argmax()))
+    assert abs(var[5].item()) <= 1e-12 and abs(mean[5].item() - bz[5].item()) <= 1e-7
+
+
+@pytest.mark.parametrize("n,h,w,fused_x", [(3, 24, 24, False), (3, 24, 24, True), (2, 23, 23, True), (8, 64, 64, True)],
+                         ids=["finalout-24x24", "x-24x24", "x-ragged-23x23", "x-64x64"])
+def test_train_epilogue_kernels_vs_torch_ops(env, n, h, w, fused_x):
+    """Epipolar in train mode (C = 256): outputs, running statistics and every gradient with the GEMM-kernel epilogue against
+    the same module on stock torch ops (EPIPOLAR_AMD.FUSED_TRAIN_EPILOGUE False: conv1x1 + batch_norm + adds, which
+    tests/test_gpu_parity.py::test_module_dropin_eval_and_train pins to the real reference)."""
+    from epipolar_transformers_amd import default_cfg, synthetic as syn
+    from epipolar_transformers_amd.epipolar import Epipolar
+
+    _lib, camera, ops = env
+    k = 16
+    P1, P2 = syn.make_pairs((n + 3) // 4, 4, 4 * h, seed=5, jitter=(0.05, 4.0))
+    P1, P2 = P1[:n], P2[:n]
+    g0 = torch.Generator().manual_seed(11)
+    f1, f2 = torch.randn(n, C, h, w, generator=g0).relu(), torch.randn(n, C, h, w, generator=g0).relu()
+    gout = torch.randn(n, C, h, w, generator=g0).cuda()
+    res = []
+    for fused in (True, False):
+        cfg = default_cfg()
+        cfg.merge_from_list(["KEYPOINT.HEATMAP_SIZE", (h, w), "KEYPOINT.NFEATS", C, "EPIPOLAR.SAMPLESIZE", k, "EPIPOLAR.ATTENTION", "avg",
+                             "EPIPOLAR.PARAMETERIZED", ("z",), "EPIPOLAR.ZRESIDUAL", True, "EPIPOLAR.USE_CORRECT_NORMALIZE", True,
+                             "DATASETS.IMAGE_SIZE", (4 * h, 4 * w), "EPIPOLAR_AMD.FUSED_TRAIN_EPILOGUE", fused])
+        torch.manual_seed(3)
+        mod = Epipolar(cfg=cfg).cuda().train()
+        with torch.no_grad():
+            mod.bn.weight.normal_(1, 0.1)
+            mod.bn.bias.normal_(0, 0.1)
+            mod.bn.running_mean.normal_(0, 0.1)
+            mod.bn.running_var.uniform_(0.5, 1.5)
+        a1, a2 = f1.cuda().requires_grad_(True), f2.cuda().requires_grad_(True)
+        called = []
+        keep = ops.z_batch_stats
+        ops.z_batch_stats = lambda *a, **kw: (called.append(1), keep(*a, **kw))[1]
+        try:
+            y = mod.forward_fused(a1, a2, P1, P2)[0] if fused_x else mod(a1, a2, P1, P2)[0]
+        finally:
+            ops.z_batch_stats = keep
+        assert bool(called) == fused
+        (y * gout).sum().backward()
+        res.append([y.detach(), mod.bn.running_mean.clone(), mod.bn.running_var.clone(), int(mod.bn.num_batches_tracked),
+                    a1.grad.clone(), a2.grad.clone()] + [q.grad.clone() for q in (mod.z.weight, mod.z.bias, mod.bn.weight, mod.bn.bias)])
+    names = ["y", "running_mean", "running_var", "num_batches_tracked", "d feat1", "d feat2", "d z.weight", "d z.bias", "d bn.weight", "d bn.bias"]
+    for nm, a, b in zip(names, *res):
+        if nm == "num_batches_tracked":
+            assert a == b == 1
+            continue
+        scale = max(b.abs().max().item(), 1e-6)
+        # (d z.bias is a sum that cancels to zero analytically -- batch norm removes the mean --: judged on the scale of d z.weight)
+        tol = 2e-4 * (res[1][6].abs().max().item() if nm == "d z.bias" else scale)
+        assert (a - b).abs().max().item() <= tol, (nm, (a - b).abs().max().item(), scale)

@@ -116,3 +116,51 @@ def test_view_shard_exchange_runs_on_rccl_with_one_rank():
     proc = subprocess.run([sys.executable, "-c", CHILD], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
                           text=True, timeout=600)
     assert proc.returncode == 0 and "rccl-1rank ok" in proc.stdout, proc.stdout[-4000:]
+
+
+@pytest.mark.parametrize("world,p2p", [(4, False), (4, True), (2, True), (8, False)], ids=["4ranks-allgather", "4ranks-p2p", "2ranks-p2p", "8ranks-allgather"])
+def test_bench_view_partition_with_several_ranks_on_one_gpu(tmp_path, world, p2p):
+    """`bench.py --gpus N --partition views` with N processes on cuda:0 (BENCH_SINGLE_DEVICE=1, gloo instead of RCCL: a 1-GPU
+    box has no second device): `layer_step_view_sharded`, `select_pairs`, the chunked exchange (all-gather and point-to-point)
+    and its range bookkeeping with world > 1 on DEVICE tensors.  Every rank dumps its maps, matrices and the x of one step;
+    the test recomputes each rank's x in this process from the maps of the rank that owns its source camera."""
+    import json
+
+    import torch
+
+    hw, frames, V = 32, 2, 4
+    env = dict(os.environ, BENCH_SINGLE_DEVICE="1", BENCH_DIST_BACKEND="gloo", BENCH_DUMP_DIR=str(tmp_path),
+               HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--partition", "views",
+           "--steps", "2", "--warmup", "1", "--frames", str(frames), "--hw", str(hw), "--samples", "16", "--exchange-chunks", "2",
+           "--no-cpu-baseline", "--no-end-to-end", "--no-other-configs"] + (["--p2p"] if p2p else [])
+    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900, cwd=ROOT)
+    assert proc.returncode == 0, proc.stdout[-4000:]
+    line = [l for l in proc.stdout.splitlines() if l.startswith("{")][-1]
+    res = json.loads(line)
+    assert res["n_gpus"] == world and res["config"]["partition"] == "views" and res["value"] > 0
+    assert ("all_to_all" in res["config"]["exchange"]) == p2p
+
+    from epipolar_transformers_amd import camera, ops
+    from epipolar_transformers_amd.parallel import ViewShardExchange
+
+    dumps = [torch.load(os.path.join(str(tmp_path), "rank%d.pt" % r)) for r in range(world)]
+    spec = ops.LayerSpec(H=hw, W=hw, K=16)
+    n = frames * V
+    for r, d in enumerate(dumps):
+        ex = ViewShardExchange(world, r, V)
+        assert d["my_cams"] == ex.my_cams and d["x"].shape[0] == n
+        f = n // len(ex.my_cams)
+        src = torch.empty_like(d["feat"])
+        for ci, cam_id in enumerate(ex.my_cams):
+            owner, idx = ex.source_location(cam_id)
+            src[ci * f:(ci + 1) * f] = dumps[owner]["feat"][idx * f:(idx + 1) * f]
+            # the matrices follow the same pairing: the source matrix of my camera is the reference matrix of its owner
+            assert torch.equal(d["P_src"][ci * f:(ci + 1) * f], dumps[owner]["P_ref"][idx * f:(idx + 1) * f])
+        cam = camera.pair_algebra(d["P_ref"], d["P_src"]).cuda()
+        packed = ops.residual_gemm_pack(d["w_fold_t"].t().contiguous().cuda())
+        x, _, _ = ops.forward_fused_nhwc(spec, d["feat"].cuda(), src.cuda(), cam, packed, d["b_fold"].cuda())
+        # (a pair's result does not depend on which pairs share its launch: the chunked step must reproduce it bit for bit)
+        assert torch.equal(x.cpu(), d["x"]), "rank %d of %d: x of the sharded step differs (max %g)" % (
+            r, world, (x.cpu() - d["x"]).abs().max().item())

@@ -214,6 +214,81 @@ def test_one_block_per_tile_split_kernel_is_stable_over_repeated_runs(shape):
         assert bool(ok.all()), "run %d: %d pixels differ" % (rep, int((~ok).sum()))
 
 
+# The fence widened (round 5): the persistent kernels and the tiled backward also run fp16 MFMAs and VALU waves side by side
+# on a SIMD.  Twenty NaN-poisoned runs each, several blocks' worth of tiles per CU, every run against one reference result.
+WS_STRESS = [pytest.param(64, 64, 64, 0, False, id="persistent-256rows-64x64-K64-N64"),
+             pytest.param(64, 64, 64, 0, True, id="persistent-256rows-fused-64x64-K64-N64"),
+             pytest.param(96, 64, 32, 0, False, id="persistent-band-96x96-K64-N32"),
+             pytest.param(96, 64, 32, 0, True, id="persistent-band-fused-96x96-K64-N32"),
+             pytest.param(48, 33, 40, 1048576, False, id="persistent-band-forced-48x48-K33-N40")]
+
+
+@pytest.mark.parametrize("H,K,N,variant,fused", WS_STRESS)
+def test_persistent_kernels_are_stable_over_repeated_runs(H, K, N, variant, fused):
+    from epipolar_transformers_amd import _lib, camera, ops, synthetic as syn
+
+    dev = torch.device("cuda:0")
+    P1, P2 = syn.make_pairs((N + 3) // 4, 4, H * 4, seed=7 + N, jitter=(0.05, 8.0))
+    P1, P2 = P1[:N], P2[:N]
+    f1, f2 = syn.make_features(N, 256, H, H, seed=9)
+    ref, src = f1.permute(0, 2, 3, 1).contiguous().to(dev), f2.permute(0, 2, 3, 1).contiguous().to(dev)
+    cam = camera.pair_algebra(P1, P2).to(dev)
+    assert ops.POISON_OUTPUTS
+    o0, a0, c0 = ops.forward_nhwc(ops.LayerSpec(H=H, W=H, K=K, variant=_lib.ET_VARIANT_NO_TILE), ref, src, cam)
+    tol_o = 1e-4 * max(1.0, o0.abs().max().item())
+    spec = ops.LayerSpec(H=H, W=H, K=K, variant=variant)
+    g = torch.Generator(device=dev).manual_seed(1)
+    wf = torch.randn(256, 256, device=dev, generator=g) * 0.05 + torch.eye(256, device=dev)
+    bias = torch.randn(256, device=dev, generator=g)
+    packed = ops.residual_gemm_pack(wf)
+    x0 = None
+    if fused:
+        x0 = (o0.double().reshape(-1, 256) @ wf.double().t() + bias.double() + ref.double().reshape(-1, 256)).float().view_as(o0)
+        tol_x = 1e-4 * max(1.0, x0.abs().max().item())
+    first = None
+    for rep in range(20):
+        if fused:
+            x, a, c = ops.forward_fused_nhwc(spec, ref, src, cam, packed, bias)
+            ok = ((a - a0).abs().amax(1) <= 1e-5) & ((x - x0).abs().amax(-1) <= tol_x) & ~torch.isnan(c).any(-1)
+            got = (x, a, c)
+        else:
+            o, a, c = ops.forward_nhwc(spec, ref, src, cam)
+            ok = ((a - a0).abs().amax(1) <= 1e-5) & ((o - o0).abs().amax(-1) <= tol_o) & ~torch.isnan(c).any(-1)
+            got = (o, a, c)
+        assert bool(ok.all()), "run %d: %d pixels differ from the per-pixel kernels" % (rep, int((~ok).sum()))
+        # the forward has no atomics: every run is the first run, bit for bit
+        if first is None:
+            first = [t.clone() for t in got]
+        else:
+            assert all(torch.equal(t, u) for t, u in zip(got, first)), "run %d differs from run 0" % rep
+    ops.check_tile_errors()
+
+
+@pytest.mark.parametrize("H,K,N", [pytest.param(64, 64, 32, id="64x64-K64-N32"), pytest.param(96, 64, 12, id="96x96-K64-N12"),
+                                   pytest.param(128, 128, 4, id="128x128-K128-N4"), pytest.param(48, 33, 24, id="48x48-K33-N24")])
+def test_tiled_backward_is_stable_over_repeated_runs(H, K, N):
+    """epipolar_bwd_tile_kernel (five split-fp16 GEMMs beside VALU phases; float atomics on d(feat_src): equal to rounding
+    only), twenty NaN-poisoned runs against the bit-reproducible gather form."""
+    from epipolar_transformers_amd import camera, ops, synthetic as syn
+
+    dev = torch.device("cuda:0")
+    P1, P2 = syn.make_pairs((N + 3) // 4, 4, H * 4, seed=11 + N, jitter=(0.05, 8.0))
+    P1, P2 = P1[:N], P2[:N]
+    f1, f2 = syn.make_features(N, 256, H, H, seed=13)
+    ref, src = f1.permute(0, 2, 3, 1).contiguous().to(dev), f2.permute(0, 2, 3, 1).contiguous().to(dev)
+    cam = camera.pair_algebra(P1, P2).to(dev)
+    gout = torch.randn(N, H, H, 256, device=dev, generator=torch.Generator(device=dev).manual_seed(3))
+    spec = ops.LayerSpec(H=H, W=H, K=K)
+    assert ops.POISON_OUTPUTS
+    gr0, gs0 = ops.backward_nhwc(spec, ref, src, cam, gout, form="gather")
+    attn = ops.forward_nhwc(spec, ref, src, cam)[1]
+    tr, ts = 1e-4 * gr0.abs().max().item(), 1e-4 * gs0.abs().max().item()
+    for rep in range(20):
+        gr, gs = ops.backward_nhwc(spec, ref, src, cam, gout, form="tile", attn=attn if rep % 2 else None)
+        bad = ((gr - gr0).abs().amax(-1) > tr) | ((gs - gs0).abs().amax(-1) > ts) | torch.isnan(gr).any(-1) | torch.isnan(gs).any(-1)
+        assert not bool(bad.any()), "run %d: %d pixels differ from the gather form" % (rep, int(bad.sum()))
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 # The same regimes where BASELINE configs[3] / [4] live: 96 x 96 maps (K = 64: epipolar_fwd_tile_kernel<1, 384>) and 128 x 128
 # maps with K = 128 (<2, 512>) -- the one-block-per-tile kernel with its split first GEMM in TWO passes, its guard and its
