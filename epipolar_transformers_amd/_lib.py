@@ -84,6 +84,9 @@ _SIGNATURES = {
     "et_residual_gemm": (ctypes.c_int, [ctypes.c_int64, ctypes.c_int32, _P, _P, _P, _P, _P, _P]),
     "et_z_batch_stats_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int64]),
     "et_z_batch_stats": (ctypes.c_int, [ctypes.c_int64, ctypes.c_int32, _P, _P, _P, _P, _P, _P, _P, ctypes.c_size_t, _P]),
+    "et_z_backward_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int64]),
+    "et_z_backward": (ctypes.c_int, [ctypes.c_int64, ctypes.c_int32, _P, _P, _P, _P, _P, _P, ctypes.c_int32, _P, _P, _P, _P, _P,
+                                     ctypes.c_size_t, _P]),
     "et_heatmap_peaks": (ctypes.c_int, [ctypes.c_int64, ctypes.c_int32, ctypes.c_int32, _P, ctypes.c_float, ctypes.c_float,
                                         ctypes.c_float, ctypes.c_int32, _P, _P, _P]),
     "et_nchw_to_nhwc": (ctypes.c_int, [ctypes.c_int32] * 4 + [_P, _P, _P]),

@@ -68,11 +68,52 @@ int et_z_batch_stats(int64_t num_pixels, int32_t C, const float *out, const void
     ET_GRANT_LDS(kern, kRgLdsBytes, dev);
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), kRgLdsBytes, st, out, (const float *)nullptr,
                        reinterpret_cast<const unsigned *>(packed_wz), z_bias, y, (long long)num_pixels,
-                       reinterpret_cast<float *>(workspace));
+                       reinterpret_cast<float *>(workspace), static_cast<const float *>(nullptr), 1);
     if (int e = check_launch("et_z_batch_stats(gemm)")) return e;
     hipLaunchKernelGGL(z_stats_finish_kernel, dim3(256), dim3(256), 0, st, reinterpret_cast<const float *>(workspace), blocks,
                        (long long)num_pixels, z_bias, mean, var);
     return check_launch("et_z_batch_stats(finish)");
+}
+
+size_t et_z_backward_workspace_bytes(int64_t num_pixels)
+{
+    if (num_pixels <= 0) return 0;
+    return (size_t)((num_pixels + kZbRows - 1) / kZbRows) * 512 * sizeof(float) + 1024 * sizeof(float);
+}
+
+// Backward of the training-mode epilogue x = bn(z(out)) [+ out] (+ feat) w.r.t. `out` and the batch norm's affine parameters,
+// from g = d loss / d x and the saved y = z(out), mean, invstd (et_z_batch_stats):
+//   grad_gamma, grad_beta (256) written;  grad_y (num_pixels, 256) written -- the batch norm's input gradient, from which the
+//   caller forms d Wz = grad_y^T out and d bz = sum grad_y with library calls;  grad_out (num_pixels, 256) written:
+//   grad_y . Wz [+ g when zresidual].  `packed_wzt` = et_residual_gemm_pack of the TRANSPOSED z weight.
+int et_z_backward(int64_t num_pixels, int32_t C, const float *g, const float *y, const float *mean, const float *invstd,
+                  const float *gamma, const void *packed_wzt, int32_t zresidual, float *grad_out, float *grad_y, float *grad_gamma,
+                  float *grad_beta, void *workspace, size_t workspace_bytes, void *stream)
+{
+    if (C != 256) return fail("et_z_backward: C = %d (the kernel is written for the 256-channel head)", C);
+    if (num_pixels <= 1) return fail("et_z_backward: bad sizes");
+    if (!g || !y || !mean || !invstd || !gamma || !packed_wzt || !grad_out || !grad_y || !grad_gamma || !grad_beta || !workspace)
+        return fail("et_z_backward: NULL pointer");
+    if (reinterpret_cast<uintptr_t>(packed_wzt) & 15) return fail("et_z_backward: packed buffer must be 16-byte aligned");
+    if (workspace_bytes < et_z_backward_workspace_bytes(num_pixels))
+        return fail("et_z_backward: workspace of %zu bytes is smaller than the %zu required", workspace_bytes,
+                    et_z_backward_workspace_bytes(num_pixels));
+    hipStream_t st = (hipStream_t)stream;
+    const int dev = current_device();
+    const long long sblocks = (num_pixels + kZbRows - 1) / kZbRows, gblocks = (num_pixels + kRgRows - 1) / kRgRows;
+    if (gblocks > 0x7fffffffLL) return fail("et_z_backward: too many rows");
+    float *partial = reinterpret_cast<float *>(workspace);
+    float *coef = partial + (size_t)sblocks * 512;
+    hipLaunchKernelGGL(z_bwd_sums_kernel, dim3((unsigned)sblocks), dim3(256), 0, st, g, y, mean, (long long)num_pixels, partial);
+    if (int e = check_launch("et_z_backward(sums)")) return e;
+    hipLaunchKernelGGL(z_bwd_finish_kernel, dim3(256), dim3(256), 0, st, partial, sblocks, (long long)num_pixels, gamma, mean, invstd,
+                       coef, grad_gamma, grad_beta);
+    if (int e = check_launch("et_z_backward(finish)")) return e;
+    auto kern = residual_gemm_kernel<true, false, true>;
+    ET_GRANT_LDS(kern, kRgLdsBytes, dev);
+    hipLaunchKernelGGL(kern, dim3((unsigned)gblocks), dim3(256), kRgLdsBytes, st, y, g, reinterpret_cast<const unsigned *>(packed_wzt),
+                       static_cast<const float *>(nullptr), grad_out, (long long)num_pixels, grad_y, coef, (int)(zresidual != 0));
+    return check_launch("et_z_backward(gemm)");
 }
 
 }  // extern "C"

@@ -74,8 +74,38 @@ class _TrainEpilogue(torch.autograd.Function):
          batch mean / variance (per-block centred sums merged pairwise in double: no cancellation, no atomics);
       2. `ops.residual_gemm` with the statistics folded into the weight: Wf = diag(gamma / sigma) Wz [+ I],
          bias = (bz - mean) gamma / sigma + beta -- the same kernel the eval path runs.
-    Backward: the library kernels autograd itself would call for these ops (aten's batch-norm and convolution backward) on the
-    saved y / out, so the gradients are the stock ones."""
+    Backward (`ops.z_backward`): one pass over g and the saved y for the batch norm's two sums, then the same GEMM kernel
+    once more -- it forms the batch norm's input gradient dy on the fly, writes it and returns d out = dy . Wz + g; only the
+    weight gradient dy^T out goes to the library (the convolution's wgrad).  Measured at Config 2 (profiles/r05_train_epilogue.txt)
+    against the alternatives kept behind two development switches: aten's own batch-norm / convolution backward on the 4-D
+    tensors (slower than autograd's stock path on channels-last memory) and plain 2-D torch ops (`_backward_rows`: the tall
+    dy^T out GEMM takes 18 ms in rocBLAS)."""
+
+    ATEN_BACKWARD = False     # development switches (scripts/train_epilogue_time.py): aten's 4-D backward ops ...
+    ROWS_BACKWARD = False     # ... or plain 2-D torch ops, instead of the et_z_backward kernels
+
+    @staticmethod
+    def _backward_rows(g4, o4, y4, zw, gamma, mean, invstd, zresidual, need_out):
+        """d out, d Wz, d bz, d gamma, d beta of x = gamma (y - mean) invstd + beta [+ out], y = out Wz^T + bz, over rows."""
+        c = o4.shape[-1]
+        g, o, y = g4.reshape(-1, c), o4.reshape(-1, c), y4.reshape(-1, c)
+        m = g.shape[0]
+        dbeta = g.sum(0)
+        gy = torch.einsum("mc,mc->c", g, y)
+        dgamma = (gy - mean * dbeta) * invstd                    # sum g yhat,  yhat = (y - mean) invstd
+        k = gamma * invstd
+        # dy = k (g - dbeta / m - yhat dgamma / m)  =  a g + b y + c0   per channel
+        b = -k * dgamma * invstd / m
+        c0 = k * (mean * invstd * dgamma - dbeta) / m
+        dy = torch.addcmul(c0, y, b).addcmul_(g, k)
+        w2 = zw.reshape(c, c)
+        dzw = (dy.t() @ o).reshape(zw.shape)
+        dzb = dy.sum(0)
+        dout = None
+        if need_out:
+            dout = (torch.addmm(g, dy, w2) if zresidual else dy @ w2).view(o4.shape)
+        return dout, dzw, dzb, dgamma, dbeta
+
 
     @staticmethod
     def forward(ctx, out, feat, zw, zb, gamma, beta, eps, zresidual):
@@ -99,6 +129,21 @@ class _TrainEpilogue(torch.autograd.Function):
     def backward(ctx, gx, _gm, _gv):
         o, y, zw, gamma, mean, invstd = ctx.saved_tensors
         g = gx.contiguous(memory_format=torch.channels_last)
+        if not (_TrainEpilogue.ATEN_BACKWARD or _TrainEpilogue.ROWS_BACKWARD):
+            # et_z_backward: the batch norm's sums (one pass over g and y), then ONE GEMM kernel that forms dy on the fly, writes
+            # it, and returns d out = dy . Wz + g; the weight gradient dy^T out is the library's convolution wgrad
+            c = o.shape[-1]
+            dout, dy, dgamma, dbeta = ops.z_backward(g.permute(0, 2, 3, 1), y, mean, invstd, gamma.detach().contiguous(),
+                                                     ops.residual_gemm_pack(zw.detach().reshape(c, c).t().contiguous()), ctx.zresidual)
+            _, dzw, dzb = torch.ops.aten.convolution_backward(dy.permute(0, 3, 1, 2), o.permute(0, 3, 1, 2), zw, [c], [1, 1], [0, 0],
+                                                             [1, 1], False, [0, 0], 1, [False, True, True])
+            return (dout.permute(0, 3, 1, 2) if ctx.needs_input_grad[0] else None, g if ctx.has_feat and ctx.needs_input_grad[1] else None,
+                    dzw, dzb, dgamma, dbeta, None, None)
+        if not _TrainEpilogue.ATEN_BACKWARD:
+            dout, dzw, dzb, dgamma, dbeta = _TrainEpilogue._backward_rows(g.permute(0, 2, 3, 1), o, y, zw, gamma, mean, invstd,
+                                                                          ctx.zresidual, bool(ctx.needs_input_grad[0]))
+            return (dout.permute(0, 3, 1, 2) if dout is not None else None, g if ctx.has_feat and ctx.needs_input_grad[1] else None,
+                    dzw, dzb, dgamma, dbeta, None, None)
         dy, dgamma, dbeta = torch.ops.aten.native_batch_norm_backward(
             g, y.permute(0, 3, 1, 2), gamma, None, None, mean, invstd, True, ctx.eps, [True, True, True])
         dout, dzw, dzb = torch.ops.aten.convolution_backward(

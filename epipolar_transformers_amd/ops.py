@@ -567,6 +567,33 @@ def z_batch_stats(out: torch.Tensor, packed_wz: torch.Tensor, z_bias: torch.Tens
     return y, mean, var
 
 
+def z_backward(g: torch.Tensor, y: torch.Tensor, mean: torch.Tensor, invstd: torch.Tensor, gamma: torch.Tensor,
+               packed_wzt: torch.Tensor, zresidual: bool):
+    """Backward of the training-mode epilogue w.r.t. `out` and the batch norm's affine parameters (et_z_backward): g, y
+    (..., 256) contiguous.  Returns (grad_out, grad_y, grad_gamma, grad_beta)."""
+    _require_gpu(g, "g")
+    _require_gpu(y, "y")
+    c = g.shape[-1]
+    if c != 256 or g.shape != y.shape or not (g.is_contiguous() and y.is_contiguous()):
+        raise ValueError("g and y must be contiguous (..., 256) tensors of one shape")
+    for t, nm in ((mean, "mean"), (invstd, "invstd"), (gamma, "gamma")):
+        if not (t.is_cuda and t.numel() == c and t.is_contiguous() and t.dtype == torch.float32):
+            raise ValueError("%s must be a contiguous float32 vector of 256 values on the GPU" % nm)
+    lib = _lib.load()
+    if packed_wzt.numel() < int(lib.et_residual_gemm_packed_bytes()) or packed_wzt.dtype != torch.uint8 or not packed_wzt.is_cuda:
+        raise ValueError("packed_wzt must be the buffer residual_gemm_pack returns")
+    rows = g.numel() // c
+    gout, gy = _empty(None, like=g), _empty(None, like=g)
+    ggamma, gbeta = _empty((c,), device=g.device), _empty((c,), device=g.device)
+    ws_bytes = int(lib.et_z_backward_workspace_bytes(rows))
+    with torch.cuda.device(g.device):
+        ws = _workspace(g.device, ws_bytes, "zbwd")
+        _lib.check(lib.et_z_backward(rows, c, _ptr(g), _ptr(y), _ptr(mean), _ptr(invstd), _ptr(gamma), _ptr(packed_wzt),
+                                     1 if zresidual else 0, _ptr(gout), _ptr(gy), _ptr(ggamma), _ptr(gbeta), _ptr(ws),
+                                     ctypes.c_size_t(ws_bytes), _stream(g)), "et_z_backward")
+    return gout, gy, ggamma, gbeta
+
+
 def heatmap_peaks(heatmaps: torch.Tensor, radius: float, downsample: float, threshold: float = 1e-6,
                   legacy_floor_division: bool = False):
     """find_tensor_peak_batch for a whole batch in ONE kernel: heatmaps (N,J,H,W) -> locations (N,J,2) in image

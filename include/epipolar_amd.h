@@ -282,6 +282,20 @@ size_t et_z_batch_stats_workspace_bytes(int64_t num_pixels);
 int et_z_batch_stats(int64_t num_pixels, int32_t C, const float *out, const void *packed_wz, const float *z_bias, float *y,
                      float *mean, float *var, void *workspace, size_t workspace_bytes, void *stream);
 
+/* Backward of that epilogue, x = bn(z(out)) [+ out] (+ feat) with batch statistics, w.r.t. `out` and the batch norm's affine
+ * parameters (ABI 12), from g = d loss / d x and what et_z_batch_stats left (y, mean, invstd = 1 / sqrt(var + eps)):
+ *   grad_gamma, grad_beta : (256) written (per-block sums merged in double, no atomics)
+ *   grad_y   : (num_pixels, 256) written: the batch norm's input gradient
+ *              gamma invstd (g - mean_rows(g) - yhat mean_rows(g yhat)),  yhat = (y - mean) invstd;
+ *              d Wz = grad_y^T out and d bz = sum_rows grad_y are left to the caller (library GEMM / reduction)
+ *   grad_out : (num_pixels, 256) written: grad_y . Wz, + g when `zresidual` (EPIPOLAR.ZRESIDUAL, epipolar.py:253)
+ * `packed_wzt` = et_residual_gemm_pack of the TRANSPOSED z weight.  d feat = g needs no kernel.
+ * workspace: et_z_backward_workspace_bytes(num_pixels) bytes, no initialisation needed. */
+size_t et_z_backward_workspace_bytes(int64_t num_pixels);
+int et_z_backward(int64_t num_pixels, int32_t C, const float *g, const float *y, const float *mean, const float *invstd,
+                  const float *gamma, const void *packed_wzt, int32_t zresidual, float *grad_out, float *grad_y, float *grad_gamma,
+                  float *grad_beta, void *workspace, size_t workspace_bytes, void *stream);
+
 /* The whole eval-mode layer as ONE data kernel (ABI 11): the sampling + attention of et_epipolar_forward_tiled with
  *     x = feat_ref + bias + out . Wf^T
  * -- `bn(z(out)) + out` (epipolar.py:250-253) and the backbone's `ret + feat` (resnet.py:388) with the eval-mode BN

@@ -237,3 +237,32 @@ def test_train_epilogue_kernels_vs_torch_ops(env, n, h, w, fused_x):
         # (d z.bias is a sum that cancels to zero analytically -- batch norm removes the mean --: judged on the scale of d z.weight)
         tol = 2e-4 * (res[1][6].abs().max().item() if nm == "d z.bias" else scale)
         assert (a - b).abs().max().item() <= tol, (nm, (a - b).abs().max().item(), scale)
+
+
+@pytest.mark.parametrize("rows,zres", [(64 * 5, True), (1587, True), (1587, False), (70000, True)], ids=["5-blocks", "ragged-1587", "ragged-no-zresidual", "70000"])
+def test_z_backward_vs_float64_autograd(env, rows, zres):
+    """et_z_backward (the batch norm's sums, then the GEMM kernel with dy formed on the fly) against float64 autograd through
+    batch_norm(out Wz^T + bz, training) [+ out]: d out, the batch norm's input gradient, d gamma, d beta."""
+    _lib, camera, ops = env
+    g0 = torch.Generator(device="cuda").manual_seed(rows)
+    out = torch.randn(rows, C, device="cuda", generator=g0).relu_()
+    wz = torch.randn(C, C, device="cuda", generator=g0) * 0.05
+    bz = torch.randn(C, device="cuda", generator=g0) * 0.1
+    gamma = 1 + 0.1 * torch.randn(C, device="cuda", generator=g0)
+    g = torch.randn(rows, C, device="cuda", generator=g0)
+    y, mean, var = ops.z_batch_stats(out, ops.residual_gemm_pack(wz), bz)
+    invstd = torch.rsqrt(var + 1e-5)
+    dout, dy, dgamma, dbeta = ops.z_backward(g, y, mean, invstd, gamma, ops.residual_gemm_pack(wz.t().contiguous()), zres)
+    dout2, dy2, dgamma2, dbeta2 = ops.z_backward(g, y, mean, invstd, gamma, ops.residual_gemm_pack(wz.t().contiguous()), zres)
+    assert torch.equal(dout, dout2) and torch.equal(dy, dy2) and torch.equal(dgamma, dgamma2) and torch.equal(dbeta, dbeta2)
+    o64 = out.double().requires_grad_(True)
+    y64 = o64 @ wz.double().t() + bz.double()
+    y64.retain_grad()
+    ga = gamma.double().requires_grad_(True)
+    be = torch.zeros(C, device="cuda", dtype=torch.float64, requires_grad=True)
+    x = torch.nn.functional.batch_norm(y64, None, None, ga, be, True, 0.1, 1e-5)
+    if zres:
+        x = x + o64
+    x.backward(g.double())
+    for nm, got, want in (("d out", dout, o64.grad), ("d y", dy, y64.grad), ("d gamma", dgamma, ga.grad), ("d beta", dbeta, be.grad)):
+        assert (got.double() - want).abs().max().item() <= 2e-5 * max(want.abs().max().item(), 1e-6), nm
