@@ -84,6 +84,8 @@ _SIGNATURES = {
     "et_residual_gemm": (ctypes.c_int, [ctypes.c_int64, ctypes.c_int32, _P, _P, _P, _P, _P, _P]),
     "et_z_batch_stats_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int64]),
     "et_z_batch_stats": (ctypes.c_int, [ctypes.c_int64, ctypes.c_int32, _P, _P, _P, _P, _P, _P, _P, ctypes.c_size_t, _P]),
+    "et_z_wgrad_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int64]),
+    "et_z_wgrad": (ctypes.c_int, [ctypes.c_int64, ctypes.c_int32, _P, _P, _P, _P, _P, ctypes.c_size_t, _P]),
     "et_z_backward_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int64]),
     "et_z_backward": (ctypes.c_int, [ctypes.c_int64, ctypes.c_int32, _P, _P, _P, _P, _P, _P, ctypes.c_int32, _P, _P, _P, _P, _P,
                                      ctypes.c_size_t, _P]),

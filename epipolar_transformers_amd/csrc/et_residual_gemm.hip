@@ -116,4 +116,42 @@ int et_z_backward(int64_t num_pixels, int32_t C, const float *g, const float *y,
     return check_launch("et_z_backward(gemm)");
 }
 
+// The weight gradient of the training-mode epilogue: grad_w (256 out x 256 in) = grad_y^T . out, grad_b (256) = sum_rows grad_y,
+// exact fp32 MFMAs, per-block partials summed in block order (no atomics).
+static int wgrad_blocks(int dev, long long rows)
+{
+    const long long steps = (rows + kWgRows - 1) / kWgRows;
+    const int cus = device_cus(dev);
+    return (int)(steps < cus ? steps : cus);
+}
+
+size_t et_z_wgrad_workspace_bytes(int64_t num_pixels)
+{
+    if (num_pixels <= 0) return 0;
+    return (size_t)wgrad_blocks(current_device(), (long long)num_pixels) * (65536 + 256) * sizeof(float);   // (one partial result per block)
+}
+
+int et_z_wgrad(int64_t num_pixels, int32_t C, const float *grad_y, const float *out, float *grad_w, float *grad_b, void *workspace,
+               size_t workspace_bytes, void *stream)
+{
+    if (C != 256) return fail("et_z_wgrad: C = %d (the kernel is written for the 256-channel head)", C);
+    if (num_pixels <= 0) return fail("et_z_wgrad: bad sizes");
+    if (!grad_y || !out || !grad_w || !grad_b || !workspace) return fail("et_z_wgrad: NULL pointer");
+    if (workspace_bytes < et_z_wgrad_workspace_bytes(num_pixels))
+        return fail("et_z_wgrad: workspace of %zu bytes is smaller than the %zu required", workspace_bytes,
+                    et_z_wgrad_workspace_bytes(num_pixels));
+    if ((long long)num_pixels * 1024 >= (1LL << 32) * 256) return fail("et_z_wgrad: too many rows");
+    hipStream_t st = (hipStream_t)stream;
+    const int dev = current_device();
+    const int blocks = wgrad_blocks(dev, (long long)num_pixels);
+    long long per = (((long long)num_pixels + blocks - 1) / blocks + kWgRows - 1) / kWgRows * kWgRows;
+    if (per * 1024 >= (1LL << 32)) return fail("et_z_wgrad: a block's share of the rows must stay below 4 GiB");
+    float *pw = reinterpret_cast<float *>(workspace), *pb = pw + (size_t)blocks * 65536;
+    ET_GRANT_LDS(z_wgrad_kernel, kWgLdsBytes, dev);
+    hipLaunchKernelGGL(z_wgrad_kernel, dim3((unsigned)blocks), dim3(512), kWgLdsBytes, st, grad_y, out, (long long)num_pixels, per, pw, pb);
+    if (int e = check_launch("et_z_wgrad")) return e;
+    hipLaunchKernelGGL(z_wgrad_finish_kernel, dim3(257), dim3(256), 0, st, pw, pb, blocks, grad_w, grad_b);
+    return check_launch("et_z_wgrad(finish)");
+}
+
 }  // extern "C"

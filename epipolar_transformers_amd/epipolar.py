@@ -83,6 +83,7 @@ class _TrainEpilogue(torch.autograd.Function):
 
     ATEN_BACKWARD = False     # development switches (scripts/train_epilogue_time.py): aten's 4-D backward ops ...
     ROWS_BACKWARD = False     # ... or plain 2-D torch ops, instead of the et_z_backward kernels
+    LIBRARY_WGRAD = False     # ... the library's 1x1 convolution wgrad instead of et_z_wgrad
 
     @staticmethod
     def _backward_rows(g4, o4, y4, zw, gamma, mean, invstd, zresidual, need_out):
@@ -135,8 +136,12 @@ class _TrainEpilogue(torch.autograd.Function):
             c = o.shape[-1]
             dout, dy, dgamma, dbeta = ops.z_backward(g.permute(0, 2, 3, 1), y, mean, invstd, gamma.detach().contiguous(),
                                                      ops.residual_gemm_pack(zw.detach().reshape(c, c).t().contiguous()), ctx.zresidual)
-            _, dzw, dzb = torch.ops.aten.convolution_backward(dy.permute(0, 3, 1, 2), o.permute(0, 3, 1, 2), zw, [c], [1, 1], [0, 0],
-                                                             [1, 1], False, [0, 0], 1, [False, True, True])
+            if _TrainEpilogue.LIBRARY_WGRAD:
+                _, dzw, dzb = torch.ops.aten.convolution_backward(dy.permute(0, 3, 1, 2), o.permute(0, 3, 1, 2), zw, [c], [1, 1], [0, 0],
+                                                                 [1, 1], False, [0, 0], 1, [False, True, True])
+            else:
+                dzw, dzb = ops.z_wgrad(dy, o)
+                dzw = dzw.view(zw.shape)
             return (dout.permute(0, 3, 1, 2) if ctx.needs_input_grad[0] else None, g if ctx.has_feat and ctx.needs_input_grad[1] else None,
                     dzw, dzb, dgamma, dbeta, None, None)
         if not _TrainEpilogue.ATEN_BACKWARD:

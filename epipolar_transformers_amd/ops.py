@@ -594,6 +594,25 @@ def z_backward(g: torch.Tensor, y: torch.Tensor, mean: torch.Tensor, invstd: tor
     return gout, gy, ggamma, gbeta
 
 
+def z_wgrad(grad_y: torch.Tensor, out: torch.Tensor):
+    """d Wz (256, 256) = grad_y^T @ out and d bz (256) = grad_y.sum(rows) over (..., 256) contiguous tensors (et_z_wgrad:
+    exact fp32 MFMAs, no atomics)."""
+    _require_gpu(grad_y, "grad_y")
+    _require_gpu(out, "out")
+    c = out.shape[-1]
+    if c != 256 or grad_y.shape != out.shape or not (grad_y.is_contiguous() and out.is_contiguous()):
+        raise ValueError("grad_y and out must be contiguous (..., 256) tensors of one shape")
+    rows = out.numel() // c
+    gw, gb = _empty((c, c), device=out.device), _empty((c,), device=out.device)
+    lib = _lib.load()
+    ws_bytes = int(lib.et_z_wgrad_workspace_bytes(rows))
+    with torch.cuda.device(out.device):
+        ws = _workspace(out.device, ws_bytes, "zwgrad")
+        _lib.check(lib.et_z_wgrad(rows, c, _ptr(grad_y), _ptr(out), _ptr(gw), _ptr(gb), _ptr(ws), ctypes.c_size_t(ws_bytes),
+                                  _stream(out)), "et_z_wgrad")
+    return gw, gb
+
+
 def heatmap_peaks(heatmaps: torch.Tensor, radius: float, downsample: float, threshold: float = 1e-6,
                   legacy_floor_division: bool = False):
     """find_tensor_peak_batch for a whole batch in ONE kernel: heatmaps (N,J,H,W) -> locations (N,J,2) in image

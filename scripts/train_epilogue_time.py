@@ -32,9 +32,10 @@ def timed(fn, reps=8):
     return sum(a.elapsed_time(b) for a, b in ev) / reps
 
 
-for label, fused, aten, rows in (("stock torch ops", False, False, False), ("GEMM kernels + aten 4-D backward", True, True, False),
-                                 ("GEMM kernels + 2-D rows backward", True, False, True),
-                                 ("GEMM kernels forward AND backward (product)", True, False, False)):
+for label, fused, aten, rows, libw in (("stock torch ops", False, False, False, False), ("GEMM kernels + aten 4-D backward", True, True, False, False),
+                                       ("GEMM kernels + 2-D rows backward", True, False, True, False),
+                                       ("GEMM kernels forward AND backward, library wgrad", True, False, False, True),
+                                       ("GEMM kernels forward AND backward + et_z_wgrad (product)", True, False, False, False)):
     cfg = default_cfg()
     cfg.merge_from_list(["KEYPOINT.HEATMAP_SIZE", (H, H), "KEYPOINT.NFEATS", C, "EPIPOLAR.PARAMETERIZED", ("z",), "EPIPOLAR.ZRESIDUAL", True,
                          "EPIPOLAR_AMD.FUSED_TRAIN_EPILOGUE", fused])
@@ -42,7 +43,7 @@ for label, fused, aten, rows in (("stock torch ops", False, False, False), ("GEM
     mod = ep.Epipolar(cfg=cfg).to(dev).train()
     with torch.no_grad():
         mod.bn.weight.normal_(1, 0.1)
-    ep._TrainEpilogue.ATEN_BACKWARD, ep._TrainEpilogue.ROWS_BACKWARD = aten, rows
+    ep._TrainEpilogue.ATEN_BACKWARD, ep._TrainEpilogue.ROWS_BACKWARD, ep._TrainEpilogue.LIBRARY_WGRAD = aten, rows, libw
     o = out.detach().requires_grad_(True)
     f = feat.detach().requires_grad_(True)
 
@@ -55,5 +56,5 @@ for label, fused, aten, rows in (("stock torch ops", False, False, False), ("GEM
         fwd().backward(gx)
 
     t_f, t_s = timed(fwd), timed(step)
-    print("%-36s forward %.3f ms   forward + backward %.3f ms   (backward %.3f)" % (label, t_f, t_s, t_s - t_f), flush=True)
-ep._TrainEpilogue.ATEN_BACKWARD = ep._TrainEpilogue.ROWS_BACKWARD = False
+    print("%-60s forward %.3f ms   forward + backward %.3f ms   (backward %.3f)" % (label, t_f, t_s, t_s - t_f), flush=True)
+ep._TrainEpilogue.ATEN_BACKWARD = ep._TrainEpilogue.ROWS_BACKWARD = ep._TrainEpilogue.LIBRARY_WGRAD = False

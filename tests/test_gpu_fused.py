@@ -266,3 +266,25 @@ def test_z_backward_vs_float64_autograd(env, rows, zres):
     x.backward(g.double())
     for nm, got, want in (("d out", dout, o64.grad), ("d y", dy, y64.grad), ("d gamma", dgamma, ga.grad), ("d beta", dbeta, be.grad)):
         assert (got.double() - want).abs().max().item() <= 2e-5 * max(want.abs().max().item(), 1e-6), nm
+
+
+@pytest.mark.parametrize("rows", [5, 16 * 7, 1587, 70000, 128 * 64 * 64], ids=["5", "112", "ragged-1587", "70000", "config2"])
+def test_z_wgrad_vs_float64(env, rows):
+    """et_z_wgrad (d Wz = dy^T out, d bz = sum dy: exact fp32 MFMAs contracted over the rows, per-block partials summed in block
+    order) against float64, and bit-reproducible."""
+    _lib, camera, ops = env
+    g0 = torch.Generator(device="cuda").manual_seed(rows)
+    dy = torch.randn(rows, C, device="cuda", generator=g0)
+    out = torch.randn(rows, C, device="cuda", generator=g0).relu_()
+    dy[:, 7] *= 1e4            # (no fp16 anywhere: magnitudes do not matter)
+    out[:, 9] *= 1e-6
+    gw, gb = ops.z_wgrad(dy, out)
+    gw2, gb2 = ops.z_wgrad(dy, out)
+    assert torch.equal(gw, gw2) and torch.equal(gb, gb2)
+    want_w = dy.double().t() @ out.double()
+    want_b = dy.double().sum(0)
+    # fp32 accumulation over `rows` terms: a few ulp of the row-wise magnitude sum
+    bound_w = 4e-7 * (dy.double().abs().t() @ out.double().abs()) + 1e-30
+    assert ((gw.double() - want_w).abs() <= bound_w * max(1.0, rows ** 0.5 / 8)).all(), ((gw.double() - want_w).abs() / bound_w).max().item()
+    bound_b = 4e-7 * dy.double().abs().sum(0) * max(1.0, rows ** 0.5 / 8) + 1e-30
+    assert ((gb.double() - want_b).abs() <= bound_b).all()
