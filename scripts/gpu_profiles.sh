@@ -4,7 +4,7 @@
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 cd "$ROOT"
 OUT="$ROOT/gpurun_out"; mkdir -p "$OUT"
-TAG=${1:-r04}
+TAG=${1:-r05}
 export HSA_ENABLE_IPC_MODE_LEGACY=0
 # ONLY="bench stats pmcbwd" gpu_profiles.sh TAG   runs those sections only (keys: bench two classic perpixel config4 config5
 #   summary stats epilogue pmcfwd pmcfused roles e2e pmcbwd general micro)
