@@ -53,6 +53,10 @@ def parse():
                     help="view partition: exchange the source maps with chunked all-to-alls in which every camera block goes "
                          "only to the rank that samples it (1 x the bytes) instead of the all-gather BASELINE.json's north star "
                          "names (G x the bytes staged); same chunking / overlap, same results")
+    ap.add_argument("--rig", default="ring",
+                    help="camera rig of the synthetic pairs (synthetic.RIGS): 'ring' is the BASELINE workload; the others (epipole "
+                         "inside / on the edge of the map, near-rectified, an H36M-like room ...) time the same batch on geometries "
+                         "the tile ordering has to cope with (frames partition only)")
     ap.add_argument("--frames", type=int, default=32, help="frames per GPU (4 views each)")
     ap.add_argument("--views", type=int, default=4)
     ap.add_argument("--hw", type=int, default=64)
@@ -141,7 +145,12 @@ def main():
 
     # ---- this rank's pairs -----------------------------------------------------------
     frames = args.frames
-    P_ref, P_src = syn.make_pairs(frames, V, image, seed=1000 + rank, jitter=(0.05, 8.0))
+    if args.rig == "ring":
+        P_ref, P_src = syn.make_pairs(frames, V, image, seed=1000 + rank, jitter=(0.05, 8.0))
+    else:
+        per_frame = 4 if args.rig == "h36m_room" else 2
+        P_ref, P_src = syn.rig_pairs(args.rig, frames * V // per_frame, image, seed=1000 + rank,
+                                     jitter=None if args.rig == "epipole_border" else (0.05, 8.0))
     n_pairs = P_ref.shape[0]                                      # frames * views
     exchange = None
     g = torch.Generator(device=dev).manual_seed(rank)
@@ -451,8 +460,9 @@ def main():
         "dtype": "f32 (split-fp16 MFMA, f32 accumulate)"
                  if split else "f32", "data": "synthetic",
         "config": {"workload": "%sepipolarposeR head, %d views x %d frames = %d pairs/GPU, C=%d, %dx%d, K=%d, "
-                               "z+BN+residual, eval" % ("configs[1]: " if (V, frames, C, H, K) == (4, 32, 256, 64, 64)
-                                                        else "", V, frames, n_pairs, C, H, W, K),
+                               "z+BN+residual, eval%s" % ("configs[1]: " if (V, frames, C, H, K, args.rig) == (4, 32, 256, 64, 64, "ring")
+                                                          else "", V, frames, n_pairs, C, H, W, K,
+                                                          "" if args.rig == "ring" else "; camera rig '%s' instead of the ring" % args.rig),
                    "partition": args.partition, "layout": "NHWC (channels_last)", "pairs_per_gpu": n_pairs,
                    "exchange": (None if exchange is None else
                                 "%d chunked %s per step, overlapped with the kernel" %
@@ -480,7 +490,16 @@ def main():
         del gout, attn_fwd
         gout = attn_fwd = None
         result["extra"]["train_step"] = train_step(dev, H, W, C, K, feat_ref, feat_src, P_ref, P_src)
-    if rank == 0 and not args.no_other_configs and (V, frames, C, H, K) == (4, 32, 256, 64, 64):
+    if tiled:
+        ws_o = ops.tile_workspace(spec, n_pairs, C, dev)
+        ops.forward_nhwc(spec, feat_ref, src, cam, workspace=ws_o)
+        torch.cuda.synchronize()
+        base_o = (-ws_o.data_ptr()) % 256
+        result["extra"]["overflow_tiles"] = {"count": int(ws_o[base_o:base_o + 4].view(torch.int32).item()),
+                                             "of": n_pairs * ((H * W + 31) // 32),
+                                             "note": "tiles the persistent kernel handed to the one-block-per-tile kernel"}
+        del ws_o
+    if rank == 0 and not args.no_other_configs and (V, frames, C, H, K, args.rig) == (4, 32, 256, 64, 64, "ring"):
         result["extra"]["config4"] = other_config(dev, hw=96, samples=64, views=4, frames=32,
                                                   name="configs[3] head: 96x96, K=64 (ResNet-152 384x384), 4 views x 32 frames = 128 pairs")
         result["extra"]["config5"] = other_config(dev, hw=128, samples=128, views=8, frames=8,

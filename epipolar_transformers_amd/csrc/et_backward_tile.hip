@@ -65,7 +65,8 @@ int et_epipolar_backward_tiled_attn(const EtLayerDesc *desc, const float *xs, co
     tp.perm = w.perm;
     tp.scales = w.scales;
     const size_t clear_vec4 = (size_t)desc->N * HW * (desc->C / 4);     // (C == 256)
-    if (int e = launch_tile_order(desc, xs, ys, cam, feat_ref, feat_src, w, tp.tiles_per_pair, false, w.scales, false,
+    // (header = true: the ordering clears the workspace's overflow counter, which the merged launch below counts into)
+    if (int e = launch_tile_order(desc, xs, ys, cam, feat_ref, feat_src, w, tp.tiles_per_pair, true, w.scales, false,
                                   reinterpret_cast<float4 *>(grad_src), clear_vec4, st, "et_epipolar_backward_tiled(order)"))
         return e;
     const int dev = current_device();
@@ -76,17 +77,37 @@ int et_epipolar_backward_tiled_attn(const EtLayerDesc *desc, const float *xs, co
                         !(desc->variant & ET_VARIANT_TILE_CLASSIC);
     const int rows = !merged ? tile_rows(desc) : tile_rows(desc) == kTileRowsSmall ? kTileRowsMerged : kTileRowsMergedLarge;
     if (merged && tp.rows_cap > rows) tp.rows_cap = rows;
-    const size_t lds = (size_t)(bwd_tile_array_floats(rows) + rows + kTilePix + 60 + kTilePix * 4) * 4 +
-                       (size_t)tp.hw_words * 8 + ((kpl == 1 && !merged) ? (size_t)kTilePix * kWave * 8 : 0);
+    auto lds_of = [&](int r, bool m) {
+        return (size_t)(bwd_tile_array_floats(r) + r + kTilePix + 60 + kTilePix * 4) * 4 + (size_t)tp.hw_words * 8 +
+               ((kpl == 1 && !m) ? (size_t)kTilePix * kWave * 8 : 0);
+    };
+    size_t lds = lds_of(rows, merged);
+    // merged launches defer the tiles beyond their columns to a second launch of the one-array kernel (unless the caller tests the
+    // splitting: ET_VARIANT_TILE_SPLIT)
+    const bool defer = merged && !(desc->variant & ET_VARIANT_TILE_SPLIT);
+    if (defer) {
+        tp.ovf_count = w.ovf_count;
+        tp.ovf_list = w.ovf_list;
+    }
 #define ET_BTILE(KK, RR)                                                                                        \
     do {                                                                                                        \
         ET_GRANT_LDS((epipolar_bwd_tile_kernel<KK, RR>), lds, dev);                                             \
         hipLaunchKernelGGL((epipolar_bwd_tile_kernel<KK, RR>), dim3((unsigned)total), dim3(256), lds, st, tp);  \
     } while (0)
-    if (rows == kTileRowsMerged) {
-        ET_BTILE(1, kTileRowsMerged);
-    } else if (rows == kTileRowsMergedLarge) {
-        ET_BTILE(1, kTileRowsMergedLarge);
+    if (rows == kTileRowsMerged || rows == kTileRowsMergedLarge) {
+        if (rows == kTileRowsMerged) ET_BTILE(1, kTileRowsMerged);
+        else ET_BTILE(1, kTileRowsMergedLarge);
+        if (defer) {
+            if (int e = check_launch("et_epipolar_backward_tiled(merged)")) return e;
+            tp.tile_list = w.ovf_list;
+            tp.tile_count = w.ovf_count;
+            tp.ovf_list = nullptr;
+            tp.ovf_count = nullptr;
+            tp.rows_cap = tile_rows_cap(desc);
+            lds = lds_of(tile_rows(desc), false);
+            if (tile_rows(desc) == kTileRowsSmall) ET_BTILE(1, kTileRowsSmall);
+            else ET_BTILE(1, kTileRowsLarge);
+        }
     } else if (rows == kTileRowsSmall) {
         if (kpl == 1) ET_BTILE(1, kTileRowsSmall);
         else if (kpl == 2) ET_BTILE(2, kTileRowsSmall);
