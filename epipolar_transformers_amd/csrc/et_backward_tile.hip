@@ -84,7 +84,11 @@ int et_epipolar_backward_tiled_attn(const EtLayerDesc *desc, const float *xs, co
     size_t lds = lds_of(rows, merged);
     // merged launches defer the tiles beyond their columns to a second launch of the one-array kernel (unless the caller tests the
     // splitting: ET_VARIANT_TILE_SPLIT)
+#ifdef ET_BWD_NO_DEFER      // (development: the A/B of profiles/r05_bwd_rigs.txt)
+    const bool defer = false;
+#else
     const bool defer = merged && !(desc->variant & ET_VARIANT_TILE_SPLIT);
+#endif
     if (defer) {
         tp.ovf_count = w.ovf_count;
         tp.ovf_list = w.ovf_list;
@@ -105,8 +109,16 @@ int et_epipolar_backward_tiled_attn(const EtLayerDesc *desc, const float *xs, co
             tp.ovf_count = nullptr;
             tp.rows_cap = tile_rows_cap(desc);
             lds = lds_of(tile_rows(desc), false);
-            if (tile_rows(desc) == kTileRowsSmall) ET_BTILE(1, kTileRowsSmall);
-            else ET_BTILE(1, kTileRowsLarge);
+            // (a few blocks per compute unit walk the list)
+            const int cus = device_cus(dev);
+            const unsigned lgrid = (unsigned)(total < 4LL * cus ? total : 4LL * cus);
+            if (tile_rows(desc) == kTileRowsSmall) {
+                ET_GRANT_LDS((epipolar_bwd_tile_list_kernel<1, kTileRowsSmall>), lds, dev);
+                hipLaunchKernelGGL((epipolar_bwd_tile_list_kernel<1, kTileRowsSmall>), dim3(lgrid), dim3(256), lds, st, tp);
+            } else {
+                ET_GRANT_LDS((epipolar_bwd_tile_list_kernel<1, kTileRowsLarge>), lds, dev);
+                hipLaunchKernelGGL((epipolar_bwd_tile_list_kernel<1, kTileRowsLarge>), dim3(lgrid), dim3(256), lds, st, tp);
+            }
         }
     } else if (rows == kTileRowsSmall) {
         if (kpl == 1) ET_BTILE(1, kTileRowsSmall);
