@@ -32,6 +32,7 @@ ET_VARIANT_TILE_CLASSIC = 65536
 ET_VARIANT_WS_SETPRIO = 262144
 ET_VARIANT_TILE_EXACT = 524288
 ET_VARIANT_WS_BAND = 1048576
+ET_VARIANT_BWD_SPLIT_IN_PLACE = 2097152
 ET_ABI_VERSION = 12
 ET_GENERAL_POOLING = 1
 ET_GENERAL_PRIOR_MUL = 2

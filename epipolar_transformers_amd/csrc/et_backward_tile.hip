@@ -84,11 +84,7 @@ int et_epipolar_backward_tiled_attn(const EtLayerDesc *desc, const float *xs, co
     size_t lds = lds_of(rows, merged);
     // merged launches defer the tiles beyond their columns to a second launch of the one-array kernel (unless the caller tests the
     // splitting: ET_VARIANT_TILE_SPLIT)
-#ifdef ET_BWD_NO_DEFER      // (development: the A/B of profiles/r05_bwd_rigs.txt)
-    const bool defer = false;
-#else
-    const bool defer = merged && !(desc->variant & ET_VARIANT_TILE_SPLIT);
-#endif
+    const bool defer = merged && !(desc->variant & (ET_VARIANT_TILE_SPLIT | ET_VARIANT_BWD_SPLIT_IN_PLACE));
     if (defer) {
         tp.ovf_count = w.ovf_count;
         tp.ovf_list = w.ovf_list;
@@ -109,9 +105,9 @@ int et_epipolar_backward_tiled_attn(const EtLayerDesc *desc, const float *xs, co
             tp.ovf_count = nullptr;
             tp.rows_cap = tile_rows_cap(desc);
             lds = lds_of(tile_rows(desc), false);
-            // (a few blocks per compute unit walk the list)
+            // (two blocks per compute unit -- what is resident at once -- walk the list)
             const int cus = device_cus(dev);
-            const unsigned lgrid = (unsigned)(total < 4LL * cus ? total : 4LL * cus);
+            const unsigned lgrid = (unsigned)(total < 2LL * cus ? total : 2LL * cus);
             if (tile_rows(desc) == kTileRowsSmall) {
                 ET_GRANT_LDS((epipolar_bwd_tile_list_kernel<1, kTileRowsSmall>), lds, dev);
                 hipLaunchKernelGGL((epipolar_bwd_tile_list_kernel<1, kTileRowsSmall>), dim3(lgrid), dim3(256), lds, st, tp);

@@ -237,7 +237,7 @@ class GeneralAttend(torch.autograd.Function):
 
 
 _TILE_BITS = (_lib.ET_VARIANT_TILE_SPLIT | _lib.ET_VARIANT_TILE_CLASSIC |
-              _lib.ET_VARIANT_WS_SETPRIO | _lib.ET_VARIANT_TILE_EXACT | _lib.ET_VARIANT_WS_BAND)   # bits that tune the tile path instead of leaving it
+              _lib.ET_VARIANT_WS_SETPRIO | _lib.ET_VARIANT_TILE_EXACT | _lib.ET_VARIANT_WS_BAND | _lib.ET_VARIANT_BWD_SPLIT_IN_PLACE)   # bits that tune the tile path instead of leaving it
 
 
 def forward_nhwc(spec: LayerSpec, ref: torch.Tensor, src: torch.Tensor, cam: torch.Tensor,

@@ -17,7 +17,7 @@ ref = torch.randn(N, H, H, C, device=dev, generator=g).relu_()
 src = torch.randn(N, H, H, C, device=dev, generator=g).relu_()
 gout = torch.randn(N, H, H, C, device=dev, generator=g)
 cam = camera.pair_algebra(P1, P2).to(dev)
-spec = ops.LayerSpec(H=H, W=H, K=K)
+spec = ops.LayerSpec(H=H, W=H, K=K, variant=int(os.environ.get("AB_VARIANT", "0")))      # (2097152: split every over-capacity tile in place)
 attn = ops.forward_nhwc(spec, ref, src, cam)[1]
 bwd = lambda: ops.backward_nhwc(spec, ref, src, cam, gout, attn=attn)
 for _ in range(3):

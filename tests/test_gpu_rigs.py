@@ -171,12 +171,30 @@ def test_backward_forms_vs_oracle_on_rig(env, oracle_mod, rig, h, k, form):
         attn = ops.forward_nhwc(spec, ref, src, cam)[1]
     gr, gs = ops.backward_nhwc(spec, ref, src, cam, ops.to_nhwc(case["g"].cuda()), form=form.split("-")[0], attn=attn)
     torch.cuda.synchronize()
-    if form.startswith("tile") and rig == "epipole_inside":
-        # most tiles around an epipole inside the map have more rows than the merged kernel's arrays hold: they must have gone
-        # through the second launch (the one-array kernel), not been split in place
+    if form.startswith("tile") and rig == "epipole_inside" and h == 64:
+        # every second tile around an epipole inside the map has more rows than the merged kernel's arrays hold: beyond the first
+        # few of the call (split in place) they must have gone through the second launch (the one-array kernel)
         assert ops.backward_deferred_tiles(ref.device) > 0
     for got, want in ((gr, case["g1"]), (gs, case["g2"])):
         got = got.permute(0, 3, 1, 2).cpu().numpy()
         assert np.isfinite(got).all()
         scale = max(float(np.abs(want).max()), 1e-30)
         assert np.abs(got - want).max() <= TOL_GRAD_REL * scale, (form, float(np.abs(got - want).max()), scale)
+
+
+def test_backward_policy_knob_split_in_place_equals_deferral(env, oracle_mod):
+    """ET_VARIANT_BWD_SPLIT_IN_PLACE (rounds 2-4: every over-capacity tile split into pixel groups in place) against the default
+    (hard tiles deferred to the one-array kernel) on the rig where every second tile is over capacity: the same gradients to
+    rounding, and only the default defers."""
+    _lib, camera, ops = env
+    case = _case(oracle_mod, camera, "epipole_inside", 64, 64)
+    ref, src, cam = ops.to_nhwc(case["f1"].cuda()), ops.to_nhwc(case["f2"].cuda()), case["cam"].cuda()
+    g = ops.to_nhwc(case["g"].cuda())
+    res = []
+    for variant in (0, _lib.ET_VARIANT_BWD_SPLIT_IN_PLACE):
+        gr, gs = ops.backward_nhwc(ops.LayerSpec(H=64, W=64, K=64, variant=variant), ref, src, cam, g, form="tile")
+        torch.cuda.synchronize()
+        res.append((gr, gs, ops.backward_deferred_tiles(ref.device)))
+    assert res[0][2] > 0 and res[1][2] == 0
+    for a, b in ((res[0][0], res[1][0]), (res[0][1], res[1][1])):
+        assert (a - b).abs().max().item() <= 2e-5 * b.abs().max().item()
