@@ -504,6 +504,7 @@ def main():
                                                   name="configs[3] head: 96x96, K=64 (ResNet-152 384x384), 4 views x 32 frames = 128 pairs")
         result["extra"]["config5"] = other_config(dev, hw=128, samples=128, views=8, frames=8,
                                                   name="configs[4] shape: 128x128, K=128 (512x512), 8 views x 8 frames = 64 pairs")
+        result["extra"]["other_rigs"] = other_rigs(dev)
     if rank == 0:
         result["extra"]["mpjpe_delta_mm_vs_reference"] = mpjpe_delta(dev)
     if rank == 0 and not args.no_end_to_end:
@@ -589,6 +590,49 @@ def ws_instance(h, w, fused):
     288-row arrays and a slot table over the tile's band up to 96 x 96)"""
     fused = fused if isinstance(fused, str) else ("true" if fused else "false")
     return ("256, 8, %s, false" if max(h, w) <= 64 else "288, 8, %s, true") % fused
+
+
+def other_rigs(dev, H=64, K=64, n=128, C=256):
+    """The headline batch on camera geometries other than the ring (synthetic.rig_pairs): the one-kernel eval layer, the tiled
+    backward with the forward's attention, and how many tiles left the fast path -- what the tile ordering and the backward's
+    over-capacity policy are worth off the BASELINE rig."""
+    from epipolar_transformers_amd import camera, ops, synthetic as syn
+
+    spec = ops.LayerSpec(H=H, W=H, K=K)
+    g = torch.Generator(device=dev).manual_seed(11)
+    ref = torch.randn(n, H, H, C, device=dev, generator=g).relu_()
+    src = torch.randn(n, H, H, C, device=dev, generator=g).relu_()
+    gout = torch.randn(n, H, H, C, device=dev, generator=g)
+    packed = ops.residual_gemm_pack(torch.randn(C, C, device=dev, generator=g) * 0.05 + torch.eye(C, device=dev))
+    bias = torch.randn(C, device=dev, generator=g)
+
+    def timed(fn, reps=8):
+        for _ in range(5):          # (the caching allocator needs a few calls to hold every output size)
+            fn()
+        torch.cuda.synchronize()
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+        for a, b in ev:
+            a.record()
+            fn()
+            b.record()
+        torch.cuda.synchronize()
+        return sum(a.elapsed_time(b) for a, b in ev) / reps
+
+    out = {}
+    for rig in ("h36m_room", "epipole_inside", "epipole_border", "near_rectified_y"):
+        P1, P2 = syn.rig_pairs(rig, n // (4 if rig == "h36m_room" else 2), 4 * H, seed=1000, jitter=None if rig == "epipole_border" else (0.05, 8.0))
+        cam = camera.pair_algebra(P1, P2).to(dev)
+        ws = ops.tile_workspace(spec, n, C, dev)
+        l_ms = timed(lambda: ops.forward_fused_nhwc(spec, ref, src, cam, packed, bias, workspace=ws))
+        base = (-ws.data_ptr()) % 256
+        ovf = int(ws[base:base + 4].view(torch.int32).item())
+        attn = ops.forward_nhwc(spec, ref, src, cam)[1]
+        b_ms = timed(lambda: ops.backward_nhwc(spec, ref, src, cam, gout, attn=attn))
+        out[rig] = {"layer_ms": l_ms, "backward_ms": b_ms, "forward_overflow_tiles": ovf,
+                    "backward_deferred_tiles": ops.backward_deferred_tiles(dev), "tiles": n * ((H * H + 31) // 32)}
+        del ws, attn
+    ops.check_tile_errors()
+    return out
 
 
 def other_config(dev, hw, samples, views, frames, name, C=256):
