@@ -504,18 +504,19 @@ def backward_nhwc(spec: LayerSpec, ref, src, cam, grad_out, use_workspace=True, 
     return g_ref, g_src
 
 
-def backward_deferred_tiles(device) -> int:
+def backward_deferred_tiles(device, header=False):
     """Tiles the most recent tiled backward on `device` (this thread, current stream) handed from the merged two-array kernel
     to the one-array kernel because their row set exceeds 192 (288) columns -- word 0 of the cached workspace.  Synchronises;
-    a diagnostic (tests, profiling)."""
+    a diagnostic (tests, profiling).  `header`: the tuple (deferred, -, four-group tiles met, eight-group tiles met early)."""
     dev = torch.device(device)
     key = (dev.type, dev.index if dev.index is not None else torch.cuda.current_device(),
            torch.cuda.current_stream(dev).cuda_stream, "fwd", threading.get_ident())
     buf = _workspaces.get(key)
     if buf is None:
-        return 0
+        return (0, 0, 0, 0) if header else 0
     base = (-buf.data_ptr()) % 256
-    return int(buf[base:base + 4].view(torch.int32).item())
+    words = buf[base:base + 16].view(torch.int32).tolist()
+    return tuple(words) if header else words[0]
 
 
 def residual_epilogue(feat, out, y=None, scale=None, shift=None, want_finalout=True, want_x=True):

@@ -83,7 +83,7 @@ typedef struct EtLayerDesc {
 #define ET_VARIANT_WS_SETPRIO 262144 /* warp-specialised kernel (first generation), tuning: s_setprio 1 on the matrix waves */
 #define ET_VARIANT_WS_BAND 1048576 /* et_epipolar_forward_tiled / _fused, testing: the persistent kernel's instance for maps above 64 x 64 (288-row arrays, slot table over the tile's band) also for smaller maps */
 #define ET_VARIANT_TILE_EXACT 524288 /* et_epipolar_forward_tiled, one-block-per-tile kernel: both GEMMs in exact fp32 (v_mfma_f32_32x32x2_f32) instead of split-fp16 products */
-#define ET_VARIANT_BWD_SPLIT_IN_PLACE 2097152 /* et_epipolar_backward_tiled: split EVERY tile beyond the merged kernel's columns in place (rounds 2-4) instead of deferring the hard ones to a second launch of the one-array kernel: 2-4 % faster on the ring rig (no second launch), up to 2 x slower on geometries with many such tiles */
+#define ET_VARIANT_BWD_SPLIT_IN_PLACE 2097152 /* et_epipolar_backward_tiled: split EVERY tile beyond the merged kernel's columns in place (rounds 2-4) instead of deferring the hard ones (those whose group chain would outlast the launch) to a second launch of the one-array kernel: equal to 3.5 % faster on the ring rig, 1.5-2 x slower on geometries with many such tiles */
 #define ET_VARIANT_BASELINE 256    /* batches of 8, compiler-chosen registers, pixels 4w..4w+3 per wave   */
 /* Bits 64 and 128 are reserved: in development builds of the library (-DET_DEV_ABLATE) they switch the per-pixel
  * kernel's tap loads off for roofline ablations (wrong results by construction); a product build rejects them. */

@@ -30,8 +30,9 @@ for a, b in ev:
     b.record()
 torch.cuda.synchronize()
 t = sorted(a.elapsed_time(b) for a, b in ev)
+hdr = ops.backward_deferred_tiles(dev, header=True)
 gr, gs = ops.backward_nhwc(spec, ref[:8], src[:8], cam[:8], gout[:8], attn=attn[:8].contiguous())
 gr2, gs2 = ops.backward_nhwc(spec, ref[:8], src[:8], cam[:8], gout[:8], form="gather")
-print("%-28s backward call %.4f ms (min %.4f, p90 %.4f) | vs gather form: d_ref %.2e of %.2e, d_src %.2e of %.2e"
+print("%-28s backward call %.4f ms (min %.4f, p90 %.4f) | vs gather form: d_ref %.2e of %.2e, d_src %.2e of %.2e | header %s"
       % (label, sum(t) / len(t), t[0], t[int(0.9 * len(t))], (gr - gr2).abs().max().item(), gr2.abs().max().item(),
-         (gs - gs2).abs().max().item(), gs2.abs().max().item()), flush=True)
+         (gs - gs2).abs().max().item(), gs2.abs().max().item(), hdr), flush=True)
