@@ -198,3 +198,38 @@ def test_backward_policy_knob_split_in_place_equals_deferral(env, oracle_mod):
     assert res[0][2] > 0 and res[1][2] == 0
     for a, b in ((res[0][0], res[1][0]), (res[0][1], res[1][1])):
         assert (a - b).abs().max().item() <= 2e-5 * b.abs().max().item()
+
+
+def test_backward_policy_branches_at_the_headline_batch(env):
+    """The over-capacity policy of the merged backward depends on a tile's POSITION in the launch (a chain of pixel groups is
+    started in place only while the launch has that much work ahead), so the small cases above never take the in-place branch
+    for eight or more groups.  The room rig at the headline batch (128 pairs, 16 384 tiles) takes every branch -- in place
+    early, deferred late, the short deferred list shared eight blocks per tile: the same gradients as with every tile split
+    in place (rounds 2-4's policy), and finite everywhere (outputs are NaN-poisoned)."""
+    _lib, camera, ops = env
+    from epipolar_transformers_amd import synthetic as syn
+    n, h, k = 128, 64, 64
+    P1, P2 = syn.rig_pairs("h36m_room", n // 4, 4 * h, seed=1000, jitter=(0.05, 8.0))
+    cam = camera.pair_algebra(P1, P2).cuda()
+    g0 = torch.Generator(device="cuda").manual_seed(11)
+    ref = torch.randn(n, h, h, C, device="cuda", generator=g0).relu_()
+    src = torch.randn(n, h, h, C, device="cuda", generator=g0).relu_()
+    gout = torch.randn(n, h, h, C, device="cuda", generator=g0)
+    attn = ops.forward_nhwc(ops.LayerSpec(H=h, W=h, K=k), ref, src, cam)[1]
+    res = []
+    for variant in (0, _lib.ET_VARIANT_BWD_SPLIT_IN_PLACE):
+        gr, gs = ops.backward_nhwc(ops.LayerSpec(H=h, W=h, K=k, variant=variant), ref, src, cam, gout, attn=attn)
+        torch.cuda.synchronize()
+        res.append((gr, gs, ops.backward_deferred_tiles(ref.device, header=True)))
+    deferred, _, _, chains_in_place = res[0][2][:4]
+    assert deferred > 0 and chains_in_place > 0, res[0][2]
+    assert res[1][2][0] == 0
+    for a, b in ((res[0][0], res[1][0]), (res[0][1], res[1][1])):
+        assert torch.isfinite(a).all() and torch.isfinite(b).all()
+        assert (a - b).abs().max().item() <= 2e-5 * b.abs().max().item()
+    # and against the bit-reproducible gather form on the pairs of the first two frames
+    m = 8
+    gr_t, gs_t = ops.backward_nhwc(ops.LayerSpec(H=h, W=h, K=k), ref[:m], src[:m], cam[:m], gout[:m], attn=attn[:m].contiguous())
+    gr_g, gs_g = ops.backward_nhwc(ops.LayerSpec(H=h, W=h, K=k), ref[:m], src[:m], cam[:m], gout[:m], form="gather")
+    for a, b in ((gr_t, gr_g), (gs_t, gs_g)):
+        assert (a - b).abs().max().item() <= 2e-5 * b.abs().max().item()
