@@ -14,8 +14,9 @@ one of them since ABI 12 (et_epipolar_backward_general: cosine, ATTENTION max, b
 gradient).  The torch restatement of the reference's op sequence (`_attend_general_chunk`, chunked over pairs) is what the
 tests compare the kernels with; the module only takes it (with an `EpipolarSlowPathWarning`) for shapes outside the
 kernel's limits (`_general_kernel_applies`) -- no shipped YAML reaches it.
-The reprojection loss and an externally supplied depth raise NotImplementedError (dead for PoseResNet, SURVEY.md a12:
-its caller unpacks four values, resnet.py:385-387).
+An externally supplied `depth` (epipolar.py:101-104, 217-218) takes the general kernel too (`_attend_with_depth`).  Only the
+reprojection loss raises NotImplementedError (dead for PoseResNet, SURVEY.md a12: its caller unpacks four values,
+resnet.py:385-387).
 """
 from __future__ import annotations
 
