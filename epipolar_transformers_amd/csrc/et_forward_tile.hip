@@ -7,31 +7,34 @@ namespace {
 #include "kernels_forward_tile_ws.inc"  // epipolar_fwd_tile_ws_kernel (warp-specialised, persistent): the default
 
 // x rows of the tiles the fused persistent kernel handed to the overflow list (their `out` rows come from the one-block-per-
-// tile kernel): x = feat_ref + bias + out . Wf^T in plain fp32, one block per tile, thread n = output channel n.  Wf is
-// rebuilt from the packed fragments (hi + lo: the 22 significant bits the matrix-core path multiplies with).  Rare path
-// (normally zero tiles): written for clarity, not speed.
+// tile kernel): x = feat_ref + bias + out . Wf^T in plain fp32, thread n = output channel n.  Wf is rebuilt from the packed
+// fragments (hi + lo: the 22 significant bits the matrix-core path multiplies with).  A block takes EIGHT pixel rows of a tile
+// (round 5: with a whole tile per block and one block per compute unit the near-rectified rig's 640 overflow tiles took 0.16 ms,
+// a fifth of the layer; profiles/r05_rig_kernel_stats.txt).  Normally the list is empty and every block leaves at once.
+constexpr int kRowsListParts = 4, kRowsListPix = kTilePix / kRowsListParts;
 __global__ __launch_bounds__(256) void residual_rows_list_kernel(const int *__restrict__ perm, const int *__restrict__ tile_list,
                                                                  const int *__restrict__ tile_count, int tiles_per_pair, int HW,
                                                                  const float *__restrict__ out, const float *__restrict__ feat,
                                                                  const unsigned *__restrict__ packed, const float *__restrict__ bias,
                                                                  float *__restrict__ x)
 {
-    __shared__ float s_out[kTilePix][256];
-    __shared__ int s_px[kTilePix];
+    __shared__ float s_out[kRowsListPix][256];
+    __shared__ int s_px[kRowsListPix];
     const int nch = threadIdx.x;                      // output channel
+    const int count = *tile_count * kRowsListParts;
+    if ((int)blockIdx.x >= count) return;
     const float inv_w = reinterpret_cast<const float *>(packed)[kRgPackedWords];
-    const int count = *tile_count;
     for (int e = blockIdx.x; e < count; e += gridDim.x) {
-        const int tile = tile_list[e];
+        const int tile = tile_list[e / kRowsListParts], part = e % kRowsListParts;
         const size_t base = (size_t)(tile / tiles_per_pair) * HW * 256;
         __syncthreads();
-        if (threadIdx.x < kTilePix) s_px[threadIdx.x] = perm[(size_t)tile * kTilePix + threadIdx.x];
+        if (threadIdx.x < kRowsListPix) s_px[threadIdx.x] = perm[(size_t)tile * kTilePix + part * kRowsListPix + threadIdx.x];
         __syncthreads();
-        for (int m = 0; m < kTilePix; ++m) s_out[m][nch] = s_px[m] >= 0 ? out[base + (size_t)s_px[m] * 256 + nch] : 0.f;
+        for (int m = 0; m < kRowsListPix; ++m) s_out[m][nch] = s_px[m] >= 0 ? out[base + (size_t)s_px[m] * 256 + nch] : 0.f;
         __syncthreads();
-        float acc[kTilePix];
+        float acc[kRowsListPix];
 #pragma unroll
-        for (int m = 0; m < kTilePix; ++m) acc[m] = 0.f;
+        for (int m = 0; m < kRowsListPix; ++m) acc[m] = 0.f;
         // fragment (ks, nb, term, lane): lane (n & 31, kg) holds Wf[n][16 ks + 8 kg .. + 7] (residual_gemm_pack_kernel)
         const int nb = nch >> 5;
         for (int ks = 0; ks < 16; ++ks)
@@ -43,11 +46,11 @@ __global__ __launch_bounds__(256) void residual_rows_list_kernel(const int *__re
                     const float w = ((float)hi[jj] + (float)lo[jj]) * inv_w;
                     const int k = ks * 16 + kg * 8 + jj;
 #pragma unroll
-                    for (int m = 0; m < kTilePix; ++m) acc[m] = fmaf(s_out[m][k], w, acc[m]);
+                    for (int m = 0; m < kRowsListPix; ++m) acc[m] = fmaf(s_out[m][k], w, acc[m]);
                 }
             }
         const float b = bias[nch];
-        for (int m = 0; m < kTilePix; ++m)
+        for (int m = 0; m < kRowsListPix; ++m)
             if (s_px[m] >= 0) {
                 const size_t o = base + (size_t)s_px[m] * 256 + nch;
                 x[o] = (feat[o] + b) + acc[m];
@@ -313,7 +316,8 @@ int et_epipolar_forward_fused(const EtLayerDesc *desc, const float *xs, const fl
         hipLaunchKernelGGL((epipolar_fwd_tile_list_kernel<1, kTileRowsSmall>), dim3(lgrid), dim3(256), lds, st, tp);
     }
     if (int e = check_launch("et_epipolar_forward_fused(list)")) return e;
-    hipLaunchKernelGGL(residual_rows_list_kernel, dim3((unsigned)(total < cus ? total : cus)), dim3(256), 0, st, w.perm,
+    const long long row_items = (long long)total * kRowsListParts;
+    hipLaunchKernelGGL(residual_rows_list_kernel, dim3((unsigned)(row_items < 8LL * cus ? row_items : 8LL * cus)), dim3(256), 0, st, w.perm,
                        w.ovf_list, w.ovf_count, tp.tiles_per_pair, HW, out_scratch, feat_ref,
                        reinterpret_cast<const unsigned *>(packed_w), bias, x);
     return check_launch("et_epipolar_forward_fused(list rows)");
