@@ -106,8 +106,18 @@ ET_HD Segment epipolar_segment(const EtLayerDesc &d, const float *cam, float gx,
 // Dividing by a power of two is the same float32 operation as multiplying by its (exact) reciprocal,
 // bit for bit, and costs one instruction instead of ~10.  The resize / downsample factors of every
 // reference config are powers of two (1, 2, 4); kernels that care test this once per launch.
+//
+// The division by the map size of `normalize` (multiview.py:30-35: / (size - 1), or / size) is NOT by a power of two,
+// but it is by a constant c: with r = RN(1 / c) (one true division per thread),
+//     q0 = RN(a r),   e = a - q0 c  (exact: one fma),   q = RN(q0 + e r)
+// is the correctly rounded quotient RN(a / c) -- Markstein's correction step; checked exhaustively on the CPU
+// (tests/test_geometry_division_cpu.py: every float a with an exponent within +-40, every divisor 2 .. 1024 the map sizes
+// produce, zero mismatches).  Three instructions instead of the ~13 of the IEEE division sequence, in the per-sample
+// chain every kernel evaluates 2 K times per reference pixel.
 struct Pow2Recips {
     float resize, predict, down;  // reciprocals, valid when ok
+    float div_w, div_h;           // the divisors of normalize for x and y: size - 1 (USE_CORRECT_NORMALIZE) or size
+    float rcp_w, rcp_h;           // RN(1 / div_w), RN(1 / div_h)
     bool ok;
 };
 
@@ -124,17 +134,34 @@ ET_HD Pow2Recips pow2_recips(const EtLayerDesc &d)
     r.resize = 1.f / d.image_resize;
     r.predict = 1.f / d.predict_resize;
     r.down = 1.f / d.downsample;
+    r.div_w = d.correct_normalize ? (float)(d.W - 1) : (float)d.W;
+    r.div_h = d.correct_normalize ? (float)(d.H - 1) : (float)d.H;
+    r.rcp_w = 1.f / r.div_w;
+    r.rcp_h = 1.f / r.div_h;
+    // (the correction step assumes a normal quotient and divisor: map sizes of 2 .. 16384 and coordinates of at most
+    //  ~1e4 pixels are far inside that; a 1-pixel map divides by zero in the reference as well)
+    r.ok = r.ok && r.div_w >= 1.f && r.div_h >= 1.f;
     return r;
+}
+
+// RN(a / c) for the constant c, rc = RN(1 / c)
+ET_HD float div_by_const(float a, float c, float rc)
+{
+    const float q0 = a * rc;
+    const float e = fmaf(-q0, c, a);
+    return fmaf(e, rc, q0);
 }
 
 // epipolar.py:411-414: /resize, coord2pix (multiview.py:163), normalize (multiview.py:30-35)
 template <bool P2>
-ET_HD float to_normalized_t(const EtLayerDesc &d, float v, int size, const Pow2Recips &pr)
+ET_HD float to_normalized_t(const EtLayerDesc &d, float v, int size, const Pow2Recips &pr, float dv = 0.f, float rc = 0.f)
 {
     if (P2) {
         v = v * pr.resize;
         v = v * pr.predict;
         v = (v + 0.5f - d.downsample / 2.0f) * pr.down;
+        if (d.correct_normalize) return -1.f + div_by_const(2.f * v, dv, rc);
+        return -1.f + div_by_const(2.f * (v + 0.5f), dv, rc);
     } else {
         v = v / d.image_resize;
         v = v / d.predict_resize;
@@ -186,8 +213,8 @@ ET_HD void sample_location(const EtLayerDesc &d, const Segment &s, float step, c
     // start + vec * step (epipolar.py:409): product rounded, then the sum
     const float lx = s.sx + s.vx * step;
     const float ly = s.sy + s.vy * step;
-    nx = to_normalized_t<P2>(d, lx, d.W, pr);
-    ny = to_normalized_t<P2>(d, ly, d.H, pr);
+    nx = to_normalized_t<P2>(d, lx, d.W, pr, pr.div_w, pr.rcp_w);
+    ny = to_normalized_t<P2>(d, ly, d.H, pr, pr.div_h, pr.rcp_h);
 }
 
 ET_HD SampleSetup sample_setup(const EtLayerDesc &d, const Segment &s, float step)

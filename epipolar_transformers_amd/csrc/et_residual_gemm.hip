@@ -145,7 +145,8 @@ int et_z_wgrad(int64_t num_pixels, int32_t C, const float *grad_y, const float *
     const int dev = current_device();
     const int blocks = wgrad_blocks(dev, (long long)num_pixels);
     long long per = (((long long)num_pixels + blocks - 1) / blocks + kWgRows - 1) / kWgRows * kWgRows;
-    if (per * 1024 >= (1LL << 32)) return fail("et_z_wgrad: a block's share of the rows must stay below 4 GiB");
+    // (the kernel forms byte offsets into a block's share as 32-bit ints: (k * 16 + row) * 1024 + chunk)
+    if ((per + kWgRows) * 1024 >= (1LL << 31)) return fail("et_z_wgrad: a block's share of the rows must stay below 2 GiB");
     float *pw = reinterpret_cast<float *>(workspace), *pb = pw + (size_t)blocks * 65536;
     ET_GRANT_LDS(z_wgrad_kernel, kWgLdsBytes, dev);
     hipLaunchKernelGGL(z_wgrad_kernel, dim3((unsigned)blocks), dim3(512), kWgLdsBytes, st, grad_y, out, (long long)num_pixels, per, pw, pb);

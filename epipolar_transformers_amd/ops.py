@@ -7,6 +7,7 @@ from __future__ import annotations
 
 import ctypes
 import threading
+import weakref
 from dataclasses import dataclass
 
 import numpy as np
@@ -347,6 +348,15 @@ def forward_fused_nhwc(spec: LayerSpec, ref: torch.Tensor, src: torch.Tensor, ca
 
 
 _workspaces = {}
+_workspaces_lock = threading.Lock()
+
+
+def _prune_dead_threads_locked():
+    """Entries of host threads that no longer exist (nn.DataParallel starts new forward threads on every call): dropped, so
+    the cache does not grow with the number of calls.  Caller holds _workspaces_lock."""
+    alive = {t.ident for t in threading.enumerate()}
+    for key in [k for k in _workspaces if k[4] not in alive]:
+        del _workspaces[key]
 
 
 def _workspace(device, nbytes: int, tag: str = "bwd") -> torch.Tensor:
@@ -355,15 +365,17 @@ def _workspace(device, nbytes: int, tag: str = "bwd") -> torch.Tensor:
     backward (tag "bwd", 3.8 GB at Config 2 -- sized for 288 GB of HBM).  One buffer per (device, stream, tag, host
     thread), grown on demand: all use is stream-ordered on the stream it is keyed by, and two host threads that launch
     on the SAME device and stream (nn.DataParallel replicas pinned to one GPU) get buffers of their own -- the cache is
-    the package's only process-wide mutable state, and no two callers ever write the same entry.
-    release_workspaces() drops them."""
+    the package's only process-wide mutable state (guarded by a lock; entries of threads that have exited are dropped
+    whenever a buffer is created), and no two callers ever write the same entry.  release_workspaces() drops them."""
     dev = torch.device(device)
     key = (dev.type, dev.index if dev.index is not None else torch.cuda.current_device(),
            torch.cuda.current_stream(dev).cuda_stream, tag, threading.get_ident())
-    buf = _workspaces.get(key)
-    if buf is None or buf.numel() < nbytes:
-        # zero-initialised ONCE (include/epipolar_amd.h): the tile forward keeps a sticky error word in it
-        _workspaces[key] = buf = torch.zeros(nbytes, dtype=torch.uint8, device=device)
+    with _workspaces_lock:
+        buf = _workspaces.get(key)
+        if buf is None or buf.numel() < nbytes:
+            _prune_dead_threads_locked()
+            # zero-initialised ONCE (include/epipolar_amd.h): the tile forward keeps a sticky error word in it
+            _workspaces[key] = buf = torch.zeros(nbytes, dtype=torch.uint8, device=device)
     return buf
 
 
@@ -392,7 +404,11 @@ def check_tile_errors(spec: "LayerSpec" = None, n: int = None, c: int = 256, wor
     reported, so that later calls are judged on their own.  Called after every tile forward when POISON_OUTPUTS is set
     (the test suite) and once per bench.py run; the product path (forward_fused_nhwc) polls the word without
     synchronising, see _poll_tile_error."""
-    bufs = [workspace] if workspace is not None else [buf for key, buf in _workspaces.items() if key[3] == "fwd"]
+    if workspace is not None:
+        bufs = [workspace]
+    else:
+        with _workspaces_lock:      # (other threads may insert meanwhile: iterate over a snapshot)
+            bufs = [buf for key, buf in list(_workspaces.items()) if key[3] == "fwd"]
     for buf in bufs:
         if buf is None or buf.numel() < 512:
             continue
@@ -404,7 +420,20 @@ def check_tile_errors(spec: "LayerSpec" = None, n: int = None, c: int = 256, wor
 
 
 _TILE_ERROR_POLL_EVERY = 16
-_error_probes = {}      # workspace data_ptr -> [calls since the last probe, pinned host word | None, event | None]
+
+
+class _ErrorProbe:
+    """Per-workspace state of the asynchronous poll: calls since the last probe, ONE pinned host word (allocated with the
+    probe, not per poll) and the event behind the copy in flight (None: no copy pending)."""
+    __slots__ = ("calls", "host", "event")
+
+    def __init__(self):
+        self.calls, self.host, self.event = 0, None, None
+
+
+# The probe hangs on the workspace TENSOR itself (an attribute: a freed workspace takes its probe with it, and a new tensor that
+# happens to get the same address starts from a clean state; a dictionary keyed by tensors would compare them element-wise).
+_PROBE_ATTR = "_et_error_probe"
 
 
 def _poll_tile_error(buf: torch.Tensor):
@@ -412,30 +441,40 @@ def _poll_tile_error(buf: torch.Tensor):
     workspace enqueues a 4-byte device-to-host copy of the word behind the kernel (pinned memory, non-blocking) and an
     event; a later call that finds the event complete reads the host copy and raises (and clears the word) if a wave
     of an EARLIER call gave up at its barrier.  A fault therefore surfaces at most ~32 calls late instead of never;
-    check_tile_errors() is the immediate, synchronising form."""
-    st = _error_probes.setdefault(buf.data_ptr(), [0, None, None])
-    if st[2] is not None and st[2].query():
-        word = int(st[1].item())
-        st[1] = st[2] = None
+    check_tile_errors() is the immediate, synchronising form.
+    Nothing happens while the stream is being captured into a graph: a copy or an event record would become part of the
+    graph, and querying an event is not allowed during a global-mode capture (it invalidates the capture).  A replayed graph
+    is therefore not polled -- call check_tile_errors() after a batch of replays."""
+    if torch.cuda.is_current_stream_capturing():
+        return
+    st = getattr(buf, _PROBE_ATTR, None)
+    if st is None:
+        st = _ErrorProbe()
+        setattr(buf, _PROBE_ATTR, st)
+    if st.event is not None and st.event.query():
+        word = int(st.host.item())
+        st.event = None
         if word:
             _clear_tile_error(buf)
             raise _lib.EpipolarAmdError((_TILE_ERROR_TEXT % word) + " -- reported by the asynchronous poll: the faulty call is "
                                         "one of the last %d on this workspace" % (2 * _TILE_ERROR_POLL_EVERY))
-    st[0] += 1
-    if st[2] is None and st[0] >= _TILE_ERROR_POLL_EVERY:
-        st[0] = 0
+    st.calls += 1
+    if st.event is None and st.calls >= _TILE_ERROR_POLL_EVERY:
+        st.calls = 0
         base = (-buf.data_ptr()) % 256
-        host = torch.empty(1, dtype=torch.int32).pin_memory()
-        host.copy_(buf[base + _TILE_ERROR_OFFSET: base + _TILE_ERROR_OFFSET + 4].view(torch.int32), non_blocking=True)
+        if st.host is None:
+            st.host = torch.empty(1, dtype=torch.int32).pin_memory()
+        st.host.copy_(buf[base + _TILE_ERROR_OFFSET: base + _TILE_ERROR_OFFSET + 4].view(torch.int32), non_blocking=True)
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream(buf.device))
-        st[1], st[2] = host, ev
+        st.event = ev
 
 
 def release_workspaces():
     """Drop every cached scratch buffer (e.g. the 3.8 GB of the gather-form backward after a training phase)."""
-    _workspaces.clear()
-    _error_probes.clear()
+    with _workspaces_lock:
+        _workspaces.clear()
+    _last_tile_backward_ws.clear()
 
 
 def tile_workspace(spec: LayerSpec, n: int, c: int, device) -> torch.Tensor:
@@ -490,6 +529,7 @@ def backward_nhwc(spec: LayerSpec, ref, src, cam, grad_out, use_workspace=True, 
             if tile_bytes == 0:
                 raise _lib.EpipolarAmdError("the tiled backward needs the 256-channel head (got C=%d, K=%d, %dx%d)" % (c, spec.K, h, w))
             ws = _workspace(ref.device, tile_bytes, "fwd")
+            _last_tile_backward_ws[(ref.device.index, torch.cuda.current_stream(ref.device).cuda_stream)] = weakref.ref(ws)
             if attn is not None:
                 assert attn.is_cuda and attn.dtype == torch.float32 and tuple(attn.shape) == (n, spec.K, h, w) and attn.is_contiguous()
             _lib.check(lib.et_epipolar_backward_tiled_attn(*args[:7], _ptr(attn), *args[7:], _ptr(ws), ctypes.c_size_t(tile_bytes),
@@ -504,14 +544,21 @@ def backward_nhwc(spec: LayerSpec, ref, src, cam, grad_out, use_workspace=True, 
     return g_ref, g_src
 
 
-def backward_deferred_tiles(device, header=False):
-    """Tiles the most recent tiled backward on `device` (this thread, current stream) handed from the merged two-array kernel
-    to the one-array kernel because their row set exceeds 192 (288) columns -- word 0 of the cached workspace.  Synchronises;
-    a diagnostic (tests, profiling).  `header`: the tuple (deferred, -, four-group tiles met, eight-group tiles met early)."""
+_last_tile_backward_ws = {}     # (device index, stream) -> weak reference to the workspace the last tiled backward ran on
+
+
+def backward_deferred_tiles(device, header=False, workspace=None):
+    """Tiles the most recent tiled backward on `device` (current stream, WHICHEVER host thread launched it: autograd runs the
+    backward on a thread of its own) handed from the merged two-array kernel to the one-array kernel because their row set
+    exceeds 192 (288) columns -- word 0 of the workspace that call used (or of `workspace`).  Synchronises; a diagnostic
+    (tests, profiling).  `header`: the tuple (deferred, -, four-group tiles met, eight-group tiles met early).  Which tiles
+    are deferred depends on the order the blocks of a launch reach them (et_tile_host.h): the count varies from run to run."""
     dev = torch.device(device)
-    key = (dev.type, dev.index if dev.index is not None else torch.cuda.current_device(),
-           torch.cuda.current_stream(dev).cuda_stream, "fwd", threading.get_ident())
-    buf = _workspaces.get(key)
+    idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    buf = workspace
+    if buf is None:
+        ref = _last_tile_backward_ws.get((idx, torch.cuda.current_stream(dev).cuda_stream))
+        buf = ref() if ref is not None else None
     if buf is None:
         return (0, 0, 0, 0) if header else 0
     base = (-buf.data_ptr()) % 256
@@ -574,8 +621,8 @@ def z_batch_stats(out: torch.Tensor, packed_wz: torch.Tensor, z_bias: torch.Tens
     y = _empty(None, like=out)
     mean = _empty((c,), device=out.device)
     var = _empty((c,), device=out.device)
-    ws_bytes = int(lib.et_z_batch_stats_workspace_bytes(rows))
     with torch.cuda.device(out.device):
+        ws_bytes = int(lib.et_z_batch_stats_workspace_bytes(rows))
         ws = _workspace(out.device, ws_bytes, "zstats")
         _lib.check(lib.et_z_batch_stats(rows, c, _ptr(out), _ptr(packed_wz), _ptr(z_bias), _ptr(y), _ptr(mean), _ptr(var), _ptr(ws),
                                         ctypes.c_size_t(ws_bytes), _stream(out)), "et_z_batch_stats")
@@ -600,8 +647,8 @@ def z_backward(g: torch.Tensor, y: torch.Tensor, mean: torch.Tensor, invstd: tor
     rows = g.numel() // c
     gout, gy = _empty(None, like=g), _empty(None, like=g)
     ggamma, gbeta = _empty((c,), device=g.device), _empty((c,), device=g.device)
-    ws_bytes = int(lib.et_z_backward_workspace_bytes(rows))
     with torch.cuda.device(g.device):
+        ws_bytes = int(lib.et_z_backward_workspace_bytes(rows))
         ws = _workspace(g.device, ws_bytes, "zbwd")
         _lib.check(lib.et_z_backward(rows, c, _ptr(g), _ptr(y), _ptr(mean), _ptr(invstd), _ptr(gamma), _ptr(packed_wzt),
                                      1 if zresidual else 0, _ptr(gout), _ptr(gy), _ptr(ggamma), _ptr(gbeta), _ptr(ws),
@@ -620,8 +667,8 @@ def z_wgrad(grad_y: torch.Tensor, out: torch.Tensor):
     rows = out.numel() // c
     gw, gb = _empty((c, c), device=out.device), _empty((c,), device=out.device)
     lib = _lib.load()
-    ws_bytes = int(lib.et_z_wgrad_workspace_bytes(rows))
     with torch.cuda.device(out.device):
+        ws_bytes = int(lib.et_z_wgrad_workspace_bytes(rows))     # (sized by the CU count of the CURRENT device: inside the guard)
         ws = _workspace(out.device, ws_bytes, "zwgrad")
         _lib.check(lib.et_z_wgrad(rows, c, _ptr(grad_y), _ptr(out), _ptr(gw), _ptr(gb), _ptr(ws), ctypes.c_size_t(ws_bytes),
                                   _stream(out)), "et_z_wgrad")
