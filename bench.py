@@ -81,7 +81,8 @@ def parse():
                          "BASELINE metric, carried in extra.end_to_end beside the layer's headline value)")
     ap.add_argument("--cpu-pairs", type=int, default=128, help="pairs in the bounded CPU-baseline sample")
     ap.add_argument("--cpu-reps", type=int, default=1)
-    ap.add_argument("--cpu-ref-pairs", type=int, default=16, help="pairs timed through the reference's op sequence at the best thread count (2 per count in the sweep)")
+    ap.add_argument("--cpu-ref-pairs", type=int, default=32, help="pairs timed through the reference's op sequence at the best thread count")
+    ap.add_argument("--cpu-sweep-pairs", type=int, default=8, help="pairs per thread count of the sweep that finds it")
     ap.add_argument("--cpu-threads", type=str, default="8,16,32,64,all", help="thread counts swept for the CPU baselines (best reported)")
     return ap.parse_args()
 
@@ -109,6 +110,52 @@ def algorithmic_bytes_per_pair(C, H, W, K):
 
 def algorithmic_flops_per_pair(C, H, W, K):
     return 12 * K * C * H * W
+
+
+def event_stats(fn, reps=10, warm=3):
+    """HIP events around `reps` calls of fn (after `warm` untimed ones): mean, min, median and max in ms -- a mean of five hides
+    whether a slow figure is every call or one outlier (the round-5 driver run: backward 10-82 % slower than any of the builder's)."""
+    for _ in range(warm):
+        fn()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+    torch.cuda.synchronize()
+    for a, b in ev:
+        a.record()
+        fn()
+        b.record()
+    torch.cuda.synchronize()
+    t = sorted(a.elapsed_time(b) for a, b in ev)
+    return {"mean": sum(t) / len(t), "min": t[0], "p50": t[len(t) // 2], "max": t[-1], "reps": reps}
+
+
+def box_info(dev):
+    """What distinguishes one box of the pool from another where the float-atomic backward is concerned: the atomic request
+    rate (ops.atomic_probe), partition modes and clocks as rocm-smi reports them, the host CPU."""
+    import subprocess
+
+    from epipolar_transformers_amd import ops
+
+    info = {}
+    try:
+        info["atomic_probe"] = ops.atomic_probe(dev)
+    except Exception as exc:
+        info["atomic_probe"] = repr(exc)[:200]
+    for key, cmd in (("partitions", ["rocm-smi", "--showcomputepartition", "--showmemorypartition"]),
+                     ("clocks", ["rocm-smi", "--showclocks"]), ("power", ["rocm-smi", "--showpower", "--showperflevel"])):
+        try:
+            out = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=20).stdout
+            info[key] = [ln.strip() for ln in out.splitlines() if ln.strip() and not set(ln.strip()) <= set("=-") and "WARNING" not in ln][:24]
+        except Exception as exc:
+            info[key] = repr(exc)[:120]
+    try:
+        with open("/proc/cpuinfo") as fh:
+            models = [ln.split(":", 1)[1].strip() for ln in fh if ln.startswith("model name")]
+        info["host_cpu"] = {"model": models[0] if models else "?", "logical_cpus": len(models)}
+    except Exception as exc:
+        info["host_cpu"] = repr(exc)[:120]
+    p = torch.cuda.get_device_properties(dev)
+    info["device"] = {"name": p.name, "cus": p.multi_processor_count, "memory_GB": p.total_memory / 2 ** 30}
+    return info
 
 
 def main():
@@ -351,21 +398,10 @@ def main():
     # fwd + bwd of the fused kernel (extra information, not the headline metric)
     gout = torch.randn_like(feat_ref)
     attn_fwd = ops.forward_nhwc(spec, feat_ref, src, cam)[1]         # what autograd saves (ops.EpipolarAttend)
-    for _ in range(2):
-        ops.backward_nhwc(spec, feat_ref, src, cam, gout, attn=attn_fwd)
-    torch.cuda.synchronize()
-    tb = time.perf_counter()
-    nb = 5
-    for _ in range(nb):
-        ops.backward_nhwc(spec, feat_ref, src, cam, gout, attn=attn_fwd)
-    torch.cuda.synchronize()
-    bwd_ms = (time.perf_counter() - tb) / nb * 1e3
-    torch.cuda.synchronize()
-    tb = time.perf_counter()
-    for _ in range(nb):
-        ops.backward_nhwc(spec, feat_ref, src, cam, gout)                # soft-max recomputed (no saved attention)
-    torch.cuda.synchronize()
-    bwd_recompute_ms = (time.perf_counter() - tb) / nb * 1e3
+    bwd_stats = event_stats(lambda: ops.backward_nhwc(spec, feat_ref, src, cam, gout, attn=attn_fwd), reps=12, warm=4)
+    bwd_ms = bwd_stats["mean"]
+    bwd_deferred = ops.backward_deferred_tiles(dev) if C == 256 else None
+    bwd_recompute_ms = event_stats(lambda: ops.backward_nhwc(spec, feat_ref, src, cam, gout), reps=6, warm=2)["mean"]   # soft-max recomputed (no saved attention)
 
     # the second kernel of the step: x = feat + bf + out @ Wf^T (HBM-bound: out and feat read, x written)
     rg = None
@@ -479,6 +515,7 @@ def main():
                                    else "per step, computed for step i+1 while the device runs step i"},
         "roofline": roofline,
         "extra": {"fused_kernel_fwd_ms": sa_kernel_ms, "layer_kernel_ms": kernel_ms, "fused_kernel_bwd_ms": bwd_ms,
+                  "fused_kernel_bwd_stats_ms": bwd_stats, "fused_kernel_bwd_deferred_tiles": bwd_deferred,
                   "fused_kernel_bwd_recompute_ms": bwd_recompute_ms,
                   "kernel_only_pair_views_per_s": n_pairs / (sa_kernel_ms * 1e-3)},
     }
@@ -506,6 +543,7 @@ def main():
                                                   name="configs[4] shape: 128x128, K=128 (512x512), 8 views x 8 frames = 64 pairs")
         result["extra"]["other_rigs"] = other_rigs(dev)
     if rank == 0:
+        result["extra"]["box"] = box_info(dev)
         result["extra"]["mpjpe_delta_mm_vs_reference"] = mpjpe_delta(dev)
     if rank == 0 and not args.no_end_to_end:
         result["extra"]["end_to_end"] = end_to_end(dev, args.hw, args.samples, args.channels, frames, V)
@@ -627,8 +665,9 @@ def other_rigs(dev, H=64, K=64, n=128, C=256):
         base = (-ws.data_ptr()) % 256
         ovf = int(ws[base:base + 4].view(torch.int32).item())
         attn = ops.forward_nhwc(spec, ref, src, cam)[1]
-        b_ms = timed(lambda: ops.backward_nhwc(spec, ref, src, cam, gout, attn=attn))
-        out[rig] = {"layer_ms": l_ms, "backward_ms": b_ms, "forward_overflow_tiles": ovf,
+        b_st = event_stats(lambda: ops.backward_nhwc(spec, ref, src, cam, gout, attn=attn), reps=8, warm=5)
+        b_ms = b_st["mean"]
+        out[rig] = {"layer_ms": l_ms, "backward_ms": b_ms, "backward_stats_ms": b_st, "forward_overflow_tiles": ovf,
                     "backward_deferred_tiles": ops.backward_deferred_tiles(dev), "tiles": n * ((H * H + 31) // 32)}
         del ws, attn
     ops.check_tile_errors()
@@ -660,9 +699,12 @@ def other_config(dev, hw, samples, views, frames, name, C=256):
         torch.cuda.synchronize()
         return sum(a.elapsed_time(b) for a, b in ev) / reps
 
-    f_ms = timed(lambda: ops.forward_nhwc(spec, ref, src, cam))
+    f_st = event_stats(lambda: ops.forward_nhwc(spec, ref, src, cam), reps=8, warm=3)
+    f_ms = f_st["mean"]
     attn = ops.forward_nhwc(spec, ref, src, cam)[1]
-    b_ms = timed(lambda: ops.backward_nhwc(spec, ref, src, cam, gout, attn=attn))
+    b_st = event_stats(lambda: ops.backward_nhwc(spec, ref, src, cam, gout, attn=attn), reps=8, warm=4)
+    b_ms = b_st["mean"]
+    b_deferred = ops.backward_deferred_tiles(dev)
     # the eval-mode layer (x = feat + bias + out . Wf^T): one kernel where the persistent kernel covers the shape (maps up to
     # 96 x 96, K <= 64), else the sample + attention kernel followed by residual_gemm_kernel
     packed = ops.residual_gemm_pack(torch.randn(C, C, device=dev, generator=g) * 0.05 + torch.eye(C, device=dev))
@@ -686,6 +728,8 @@ def other_config(dev, hw, samples, views, frames, name, C=256):
             "layer_ms": l_ms, "layer_pair_views_per_s": n / (l_ms * 1e-3),
             "layer_kernels": (ws_name % "true") if one_kernel else "the forward kernel + residual_gemm_kernel",
             "backward_ms": b_ms, "backward_frac_of_hbm_peak": bb / (b_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "forward_stats_ms": f_st, "backward_stats_ms": b_st, "backward_deferred_tiles": b_deferred,
+            "tiles": n * ((hw * hw + 31) // 32),
             "algorithmic_bytes_forward": fb, "algorithmic_bytes_backward": bb}
 
 
@@ -766,6 +810,14 @@ def mpjpe_delta(dev):
     return float(mpjpe(x_new, x_ref))
 
 
+def _cpu_model():
+    try:
+        with open("/proc/cpuinfo") as fh:
+            return next(ln.split(":", 1)[1].strip() for ln in fh if ln.startswith("model name"))
+    except Exception:
+        return "?"
+
+
 def cpu_baseline(args, spec, feat_ref, feat_src, P_ref, P_src, gpu_same_scope):
     """The reference CPU path on this box's host cores, on a bounded sample of the same workload, each implementation at
     the thread count that is FASTEST for it (swept: --cpu-threads; the box's full thread count oversubscribes both):
@@ -790,7 +842,7 @@ def cpu_baseline(args, spec, feat_ref, feat_src, P_ref, P_src, gpu_same_scope):
     f2 = feat_src[:n_t].permute(0, 3, 1, 2).contiguous().cpu().numpy()
     locs = orc.sample_locs(ospec, P_ref[:n_t], P_src[:n_t])
     sweep_t = {}
-    n_s = min(2, n_t)                                                           # per thread count of the sweep
+    n_s = min(args.cpu_sweep_pairs, n_t)                                        # per thread count of the sweep
     for th in counts:
         trp.forward_timed(f1[:1], f2[:1], locs[:, :1], th)                      # warm-up (first call ~2.5x slower)
         dt_t, _ = trp.forward_timed(f1[:n_s], f2[:n_s], locs[:, :n_s], th)
@@ -802,7 +854,7 @@ def cpu_baseline(args, spec, feat_ref, feat_src, P_ref, P_src, gpu_same_scope):
     # does not exist on the GPU box) and "port"; this is a port that keeps the reference's op sequence
     ref = {"value": sweep_t[best_t], "unit": "pair-views/s", "cores": best_t, "kind": "port",
            "implementation": "reference-op-sequence (oracle/torch_ref_path.py, PyTorch CPU)",
-           "threads_swept": {str(k): v for k, v in sweep_t.items()}, "host_threads": cores,
+           "threads_swept": {str(k): v for k, v in sweep_t.items()}, "host_threads": cores, "host_cpu": _cpu_model(),
            "gpu_same_scope_value": gpu_same_scope,
            "sample": "%d of the %d pairs of one GPU's batch at the best thread count (%d; found with %d pairs each at %s "
                      "threads), fused sample+attention only (no z/BN), the reference's per-pair op sequence "

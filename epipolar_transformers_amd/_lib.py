@@ -33,7 +33,7 @@ ET_VARIANT_WS_SETPRIO = 262144
 ET_VARIANT_TILE_EXACT = 524288
 ET_VARIANT_WS_BAND = 1048576
 ET_VARIANT_BWD_SPLIT_IN_PLACE = 2097152
-ET_ABI_VERSION = 12
+ET_ABI_VERSION = 13
 ET_GENERAL_POOLING = 1
 ET_GENERAL_PRIOR_MUL = 2
 ET_GENERAL_COSINE = 4
@@ -95,6 +95,7 @@ _SIGNATURES = {
     "et_nchw_to_nhwc": (ctypes.c_int, [ctypes.c_int32] * 4 + [_P, _P, _P]),
     "et_nhwc_to_nchw": (ctypes.c_int, [ctypes.c_int32] * 4 + [_P, _P, _P]),
     "et_debug_host_sample_setup": (ctypes.c_int, [_D, _P, _P, _P, _P, ctypes.c_int32, ctypes.c_int32, _P, _P, _P]),
+    "et_debug_atomic_probe": (ctypes.c_int, [_P, ctypes.c_int64, ctypes.c_int32, ctypes.c_int32, _P]),
 }
 
 _lib = None

@@ -86,6 +86,13 @@ int et_debug_host_sample_setup(const EtLayerDesc *desc, const float *xs, const f
     return 0;
 }
 
+int et_debug_atomic_probe(float *dst, int64_t rows, int32_t blocks, int32_t iters, void *stream)
+{
+    if (!dst || rows < 8 || rows > (1LL << 22) - 1 || blocks <= 0 || iters <= 0) return fail("et_debug_atomic_probe: bad arguments");
+    hipLaunchKernelGGL(atomic_probe_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, dst, (unsigned)rows, iters);
+    return check_launch("et_debug_atomic_probe");
+}
+
 int et_heatmap_peaks(int64_t num_maps, int32_t H, int32_t W, const float *heatmaps, float radius, float downsample,
                      float threshold, int32_t legacy_floor_division, float *locs, float *scores, void *stream)
 {

@@ -287,10 +287,44 @@ class Epipolar(nn.Module):
         m2 = self.g(other2) if "g" in e.PARAMETERIZED else other2                       # :152-153
         with torch.no_grad():
             cam = self._cam(P1, P2, feat2.device)
+        w = w.to(feat2)
+        if not (feat2.is_cuda and bool(amd_knob(self.cfg, "GENERAL_KERNEL", True)) and not (e.POOLING and self.sample_size % 2)
+                and rows <= 256):
+            # what the general kernel does not take (the same limits as _general_kernel_applies: CPU tensors are refused by
+            # ops, EPIPOLAR_AMD.GENERAL_KERNEL False, an odd K with POOLING, more than 256 weights per pixel): the reference's
+            # op sequence in torch, as for every other branch
+            return self._attend_with_depth_torch(m2, w, cam)
         unused = feat2.new_zeros((feat2.shape[0], 4, self.feat_h, self.feat_w))        # (q / similarity map: not read in this mode)
         mode = dict(prior_mul=False, cosine=False, attention_max=e.ATTENTION == "max", sim_prior=True)
         out, _, corr_pos = ops.GeneralAttend.apply(unused, unused, m2, cam, self.layer_spec(), bool(e.POOLING),
-                                                   w.to(feat2).contiguous(), mode)
+                                                   w.contiguous(), mode)
+        return out, w, corr_pos
+
+    def _attend_with_depth_torch(self, m2, w, cam):
+        """The supplied-depth branch as torch ops (epipolar.py:199-213, 225-243 with `sim` = the given weights): the route of
+        shapes the general kernel does not take.  `cam`: the per-pair algebra, computed once by the caller."""
+        _warn_slow_path(self.cfg)
+        e = self.cfg.EPIPOLAR
+        K, H, W = self.sample_size, self.feat_h, self.feat_w
+        N, c = m2.shape[0], m2.shape[1]
+        with torch.no_grad():
+            locs = ops.sample_locs(self.layer_spec(), cam)                    # (K,N,H,W,2)
+        grid = locs.permute(1, 0, 2, 3, 4).reshape(N, K * H, W, 2)
+        s2 = F.grid_sample(m2, grid, mode="bilinear", padding_mode="zeros",
+                           align_corners=bool(amd_knob(self.cfg, "ALIGN_CORNERS", False))).view(N, c, K, H, W).permute(0, 2, 1, 3, 4)
+        if e.POOLING:
+            s2 = s2.reshape(N, 2, K // 2, c, H, W).max(1)[0]
+        idx = w.argmax(1)
+        with torch.no_grad():
+            pos = torch.gather(locs.permute(1, 0, 2, 3, 4), 1, idx.view(N, 1, H, W, 1).expand(-1, -1, -1, -1, 2)).squeeze(1)
+            if e.USE_CORRECT_NORMALIZE:
+                corr_pos = torch.stack([(pos[..., 0] + 1) * (W - 1) / 2, (pos[..., 1] + 1) * (H - 1) / 2], -1)
+            else:
+                corr_pos = torch.stack([(pos[..., 0] + 1) * W / 2 - 0.5, (pos[..., 1] + 1) * H / 2 - 0.5], -1)
+        if e.ATTENTION == "max":
+            out = torch.gather(s2, 1, idx.view(N, 1, 1, H, W).expand(-1, -1, c, -1, -1)).squeeze(1)
+        else:
+            out = (s2 * w.unsqueeze(2)).sum(1)
         return out, w, corr_pos
 
     def _attend_general_hip(self, feat1, feat2, P1, P2, camera=None, other_camera=None, ref1=None, ref2=None):

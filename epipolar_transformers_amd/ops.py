@@ -566,6 +566,29 @@ def backward_deferred_tiles(device, header=False, workspace=None):
     return tuple(words) if header else words[0]
 
 
+def atomic_probe(device, rows: int = 1 << 18, blocks: int = 2048, iters: int = 256, reps: int = 5) -> dict:
+    """Float-atomic request rate of this box (et_debug_atomic_probe: the access pattern of the tiled backward's d(feat_src)
+    accumulation -- one buffer_atomic_fadd_f32 wave-instruction = two 128-byte runs in two pixel rows -- on pseudo-random rows of
+    a (rows, 256) fp32 array, 1 GB by default, nothing else in the kernel).  A diagnostic for bench.py: synchronises."""
+    dev = torch.device(device)
+    dst = torch.zeros(rows, 256, device=dev)
+    lib = _lib.load()
+    ms = []
+    with torch.cuda.device(dev):
+        for r in range(reps + 1):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            _lib.check(lib.et_debug_atomic_probe(_ptr(dst), rows, blocks, iters, _stream(dst)), "et_debug_atomic_probe")
+            b.record()
+            torch.cuda.synchronize(dev)
+            if r:
+                ms.append(a.elapsed_time(b))
+    ms.sort()
+    n_instr = blocks * 4 * iters
+    return {"array_MB": rows * 1024 / 1e6, "wave_instructions": n_instr, "ms_min": ms[0], "ms_p50": ms[len(ms) // 2], "ms_max": ms[-1],
+            "G_wave_atomics_per_s": n_instr / (ms[len(ms) // 2] * 1e-3) / 1e9, "GB_per_s": n_instr * 256 / (ms[len(ms) // 2] * 1e-3) / 1e9}
+
+
 def residual_epilogue(feat, out, y=None, scale=None, shift=None, want_finalout=True, want_x=True):
     """All (N,H,W,C) contiguous.  finalout = out + y*scale + shift ; x = feat + finalout."""
     n, h, w, c = out.shape

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define ET_ABI_VERSION 12
+#define ET_ABI_VERSION 13
 
 /* Static description of one layer call: the cfg keys the reference reads in
  * Epipolar.__init__ (epipolar.py:12-54) and at call time (epipolar.py:303-311,
@@ -348,6 +348,12 @@ int et_nhwc_to_nchw(int32_t N, int32_t C, int32_t H, int32_t W, const float *src
 int et_debug_host_sample_setup(const EtLayerDesc *desc, const float *xs, const float *ys,
                                const float *steps, const float *cam, int32_t h, int32_t w,
                                int32_t *taps, float *weights, float *locs);
+
+/* Diagnostic (no reference counterpart; bench.py reports it beside the backward's time): `blocks` x 4 waves each issue
+ * `iters` float-atomic wave-instructions onto pseudo-random pixel rows of dst (rows, 256) fp32 -- the access pattern of the
+ * tiled backward's d(feat_src) accumulation (two 128-byte runs in two rows per instruction) with nothing around it.  dst is
+ * modified (1.0 is added); rows < 2^22. */
+int et_debug_atomic_probe(float *dst, int64_t rows, int32_t blocks, int32_t iters, void *stream);
 
 #ifdef __cplusplus
 }

@@ -11,7 +11,12 @@ label = sys.argv[1] if len(sys.argv) > 1 else os.path.basename(os.environ.get("E
 dev = torch.device("cuda:0")
 H, C, K = (int(os.environ.get(k, v)) for k, v in (("AB_H", 64), ("AB_C", 256), ("AB_K", 64)))
 N = int(os.environ.get("AB_N", 128))
-P1, P2 = syn.make_pairs(N // 4, 4, H * 4, seed=1000, jitter=(0.05, 8.0))
+RIG = os.environ.get("AB_RIG", "ring")           # (ring | h36m_room | epipole_inside | epipole_border | near_rectified_y: synthetic.rig_pairs)
+if RIG == "ring":
+    P1, P2 = syn.make_pairs(N // 4, 4, H * 4, seed=1000, jitter=(0.05, 8.0))
+else:
+    P1, P2 = syn.rig_pairs(RIG, N // (4 if RIG == "h36m_room" else 2), 4 * H, seed=1000, jitter=None if RIG == "epipole_border" else (0.05, 8.0))
+label += " [%s]" % RIG
 g = torch.Generator(device=dev).manual_seed(0)
 ref = torch.randn(N, H, H, C, device=dev, generator=g).relu_()
 src = torch.randn(N, H, H, C, device=dev, generator=g).relu_()

@@ -4,10 +4,10 @@
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 cd "$ROOT"
 OUT="$ROOT/gpurun_out"; mkdir -p "$OUT"
-TAG=${1:-r05}
+TAG=${1:-r06}
 export HSA_ENABLE_IPC_MODE_LEGACY=0
 # ONLY="bench stats pmcbwd" gpu_profiles.sh TAG   runs those sections only (keys: bench two classic perpixel config4 config5
-#   summary stats epilogue pmcfwd pmcfused roles e2e pmcbwd general micro)
+#   summary stats shapestats epilogue pmcfwd pmcfused roles e2e pmcbwd general micro)
 want() { [ -z "$ONLY" ] || [[ " $ONLY " == *" $1 "* ]]; }
 stats() {  # stats NAME -- bench args...   : rocprofv3 --kernel-trace --stats of a bench run, keep the kernel_stats csv
   local name=$1; shift
@@ -37,6 +37,27 @@ echo "== rocprof kernel stats"
 stats bench --steps 10 --warmup 3 --no-cpu-baseline
 stats config4 --steps 5 --warmup 2 --no-cpu-baseline --hw 96
 stats config5 --steps 5 --warmup 2 --no-cpu-baseline --samples 128 --hw 128 --frames 8 --views 8
+}
+# one rocprofv3 --kernel-trace --stats file PER (kernel family, shape): scripts/profile_kernel.py launches exactly one call size, so
+# AverageNs in these files is the time of that shape (the stats of a whole bench run mix the call sizes of every config it times)
+shape_stats() {  # shape_stats NAME  (PROF_* in the environment)
+  local name=$1
+  (cd /tmp && export TMPDIR=/tmp && PROF_REPS=10 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_${TAG}_$name" -o trace -- \
+      python "$ROOT/scripts/profile_kernel.py" > "$OUT/${TAG}_${name}_rocprof.log" 2>&1)
+  local f=$(find "$OUT/prof_${TAG}_$name" -name "*kernel_stats.csv" | head -1)
+  [ -n "$f" ] && cp "$f" "$OUT/${TAG}_shape_${name}_kernel_stats.csv" && head -4 "$f"
+  rm -rf "$OUT/prof_${TAG}_$name"
+}
+want shapestats && {
+echo "== rocprof kernel stats, one shape per file"
+PROF_KERNEL=fused shape_stats config2_layer
+PROF_KERNEL=fwd shape_stats config2_forward
+PROF_KERNEL=bwd shape_stats config2_backward
+PROF_KERNEL=fused PROF_HW=96 shape_stats config4_layer
+PROF_KERNEL=fwd PROF_HW=96 shape_stats config4_forward
+PROF_KERNEL=bwd PROF_HW=96 shape_stats config4_backward
+PROF_KERNEL=fwd PROF_HW=128 PROF_K=128 PROF_PAIRS=64 PROF_VIEWS=8 shape_stats config5_forward
+PROF_KERNEL=bwd PROF_HW=128 PROF_K=128 PROF_PAIRS=64 PROF_VIEWS=8 shape_stats config5_backward
 }
 want epilogue && {
 echo "== residual epilogue kernel"

@@ -14,10 +14,11 @@ variant = int(os.environ.get("PROF_VARIANT", 0))
 which = os.environ.get("PROF_KERNEL", "fwd")
 H, C, K = int(os.environ.get("PROF_HW", 64)), 256, int(os.environ.get("PROF_K", 64))
 dev = torch.device("cuda:0")
-P1, P2 = syn.make_pairs(32, 4, H * 4, seed=1000, jitter=(0.05, 8.0))
+NP, V = int(os.environ.get("PROF_PAIRS", 128)), int(os.environ.get("PROF_VIEWS", 4))      # (Config 5: PROF_PAIRS=64 PROF_VIEWS=8)
+P1, P2 = syn.make_pairs(NP // V, V, H * 4, seed=1000, jitter=(0.05, 8.0))
 g = torch.Generator(device=dev).manual_seed(0)
-ref = torch.randn(128, H, H, C, device=dev, generator=g).relu_()
-src = torch.randn(128, H, H, C, device=dev, generator=g).relu_()
+ref = torch.randn(NP, H, H, C, device=dev, generator=g).relu_()
+src = torch.randn(NP, H, H, C, device=dev, generator=g).relu_()
 cam = camera.pair_algebra(P1, P2).to(dev)
 spec = ops.LayerSpec(H=H, W=H, K=K, variant=variant)
 attn = ops.forward_nhwc(spec, ref, src, cam)[1] if which == "bwd" else None      # what autograd hands the backward

@@ -4,7 +4,7 @@
 
 Writes tests/golden/modes/<name>.npz: inputs, the reference module's parameters (incl. the unregistered `prior`
 tables), the reference's per-pair camera algebra on this machine, and its outputs in eval mode
-(finalout, corr_pos, depth) plus autograd gradients of sum(finalout * grad_out) w.r.t. both feature maps.
+(finalout, corr_pos, depth) plus autograd gradients of sum(finalout * grad_out) w.r.t. both feature maps (and w.r.t. the prior tables: priorgrad.<i>.<j>).
 Runs only in the build container (needs /root/reference)."""
 import os
 import sys
@@ -33,6 +33,10 @@ CASES = [
                                                "EPIPOLAR.PARAMETERIZED", "()"]),
     dict(name="prior_mul_c8_k8", C=8, K=8, ov=["EPIPOLAR.PRIOR", "True", "EPIPOLAR.PRIORMUL", "True",
                                                "DATASETS.CAMERAS", "(1, 2, 3, 4)", "EPIPOLAR.PARAMETERIZED", "()"]),
+    # SIMILARITY prior (epipolar.py:288-289): the learned table IS the weight -- returned before the mask, the scale and the
+    # soft-max; no gradient reaches feat1, the table's own gradient is sum_c g_c S_kc
+    dict(name="similarity_prior_c8_k8", C=8, K=8, ov=["EPIPOLAR.SIMILARITY", "prior", "EPIPOLAR.PRIOR", "True",
+                                                      "DATASETS.CAMERAS", "(1, 2, 3, 4)", "EPIPOLAR.PARAMETERIZED", "()"]),
     dict(name="rgb_corr_c8_k8", C=8, K=8, ov=["EPIPOLAR.FIND_CORR", "rgb", "EPIPOLAR.OTHER_GRAD", "('other2',)",
                                               "EPIPOLAR.PARAMETERIZED", "()"]),
     # an externally supplied `depth` (epipolar.py:101-104, 217-218, 249): the given weights replace the similarity, no z
@@ -45,8 +49,9 @@ CASES = [
 def run_case(c):
     ov = ["KEYPOINT.HEATMAP_SIZE", "(%d, %d)" % (H, H), "KEYPOINT.NFEATS", str(c["C"]), "EPIPOLAR.SAMPLESIZE", str(c["K"]),
           "DATASETS.IMAGE_SIZE", "(%d, %d)" % (IMAGE, IMAGE), "EPIPOLAR.USE_CORRECT_NORMALIZE", "True"] + c["ov"]
-    mod, cfg = rh.reference_epipolar(overrides=ov)
     seed = sum(map(ord, c["name"])) % 1000
+    torch.manual_seed(seed)            # (the reference draws its prior tables from the global generator, epipolar.py:79-80)
+    mod, cfg = rh.reference_epipolar(overrides=ov)
     P1, P2 = syn.make_pairs(1, 4, IMAGE, seed=seed, jitter=(0.05, 3.0))
     N = P1.shape[0]
     f1, f2 = syn.make_features(N, c["C"], H, H, seed=seed)
@@ -91,6 +96,8 @@ def run_case(c):
         data["sd." + k] = npf(v) if v.dtype.is_floating_point else v.numpy()
     for (i, j), v in getattr(mod, "prior", {}).items():
         data["prior.%d.%d" % (i, j)] = npf(v)
+        # the table's own gradient (epipolar.py:300-301, 308-309, 288-289); a pair no sample uses gets none: zeros
+        data["priorgrad.%d.%d" % (i, j)] = npf(v.grad) if v.grad is not None else np.zeros_like(npf(v))
     return data
 
 

@@ -288,3 +288,43 @@ def test_z_wgrad_vs_float64(env, rows):
     assert ((gw.double() - want_w).abs() <= bound_w * max(1.0, rows ** 0.5 / 8)).all(), ((gw.double() - want_w).abs() / bound_w).max().item()
     bound_b = 4e-7 * dy.double().abs().sum(0) * max(1.0, rows ** 0.5 / 8) + 1e-30
     assert ((gb.double() - want_b).abs() <= bound_b).all()
+
+
+def test_error_poll_is_asynchronous_and_survives_graph_capture(env, monkeypatch):
+    """The product path (POISON_OUTPUTS off) polls the workspace's sticky error word without synchronising: every 16th call
+    queues a 4-byte copy + an event.  Neither may happen while the stream is captured into a graph -- a copy / event record
+    would become part of the graph and Event.query() invalidates a global-mode capture -- and the probe's state
+    hangs on the workspace tensor, so a new workspace starts clean."""
+    _lib, camera, ops = env
+    monkeypatch.setattr(ops, "POISON_OUTPUTS", False)
+    n, h, k = 4, 32, 16
+    P1, P2, f1, f2, wf, bias = _inputs(n, h, seed=7)
+    spec = ops.LayerSpec(H=h, W=h, K=k)
+    ref, src = ops.to_nhwc(f1.cuda()), ops.to_nhwc(f2.cuda())
+    cam = camera.pair_algebra(P1, P2).cuda()
+    packed, bias_d = ops.residual_gemm_pack(wf.cuda()), bias.cuda()
+    ws = ops.tile_workspace(spec, n, C, ref.device)
+    x0 = ops.forward_fused_nhwc(spec, ref, src, cam, packed, bias_d, workspace=ws)[0]
+    for _ in range(40):                      # > 2 polls: copies queued, events queried, nothing raised
+        ops.forward_fused_nhwc(spec, ref, src, cam, packed, bias_d, workspace=ws)
+    probe = getattr(ws, ops._PROBE_ATTR)
+    assert probe.host is not None and probe.host.is_pinned()
+    # a probe is pending or about to be due: capture now
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(side):
+        for _ in range(15):
+            ops.forward_fused_nhwc(spec, ref, src, cam, packed, bias_d, workspace=ws)
+        calls_before = getattr(ws, ops._PROBE_ATTR).calls
+        with torch.cuda.graph(graph, stream=side):
+            xg = ops.forward_fused_nhwc(spec, ref, src, cam, packed, bias_d, workspace=ws)[0]
+        assert getattr(ws, ops._PROBE_ATTR).calls == calls_before, "the poll must not run during capture"
+    torch.cuda.current_stream().wait_stream(side)
+    for _ in range(3):
+        graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(xg, x0)
+    ops.check_tile_errors(workspace=ws)
+    ws2 = ops.tile_workspace(spec, n, C, ref.device)
+    assert getattr(ws2, ops._PROBE_ATTR, None) is None

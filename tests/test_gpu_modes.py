@@ -103,6 +103,62 @@ def test_mode_vs_reference(name):
         gd = kw["depth"].grad
         gd = np.zeros_like(d["grad_depth"]) if gd is None else gd.cpu().numpy()
         assert np.abs(gd - d["grad_depth"]).max() <= 1e-4 * max(float(np.abs(d["grad_depth"]).max()), 1e-6)
+    _check_prior_grads(mod, d)
+
+
+def _check_prior_grads(mod, d):
+    """the prior tables' OWN gradient against the reference's autograd (epipolar.py:288-289, 300-301, 308-309): priorgrad.<i>.<j>
+    of the fixture; a pair no sample of the batch uses gets no gradient there (zeros)"""
+    keys = [k for k in d.files if k.startswith("priorgrad.")]
+    if not keys:
+        return
+    scale = max(max(float(np.abs(d[k]).max()) for k in keys), 1e-6)
+    assert scale > 1e-3, "the fixture was meant to carry a gradient for the prior tables"
+    for k in keys:
+        _, i, j = k.split(".")
+        g = mod.prior[(int(i), int(j))].grad
+        g = np.zeros_like(d[k]) if g is None else g.cpu().numpy()
+        assert np.abs(g - d[k]).max() <= 1e-4 * scale, (k, float(np.abs(g - d[k]).max()), scale)
+
+
+@pytest.mark.parametrize("name", MODES)
+def test_torch_restatement_vs_reference(name):
+    """`Epipolar._attend_general_chunk` -- the torch restatement of epipolar.py:131-247 / 272-321 that the "vs the restatement"
+    tests of the general kernels lean on, and the route of shapes those kernels do not take -- pinned to the same outputs of
+    the real reference as the HIP route above (EPIPOLAR_AMD.GENERAL_KERNEL False forces it)."""
+    import warnings
+
+    from epipolar_transformers_amd.epipolar import EpipolarSlowPathWarning
+
+    d = np.load(os.path.join(GOLDEN_DIR, "modes", name + ".npz"))
+    mod = _module(d)
+    mod.cfg.defrost() if hasattr(mod.cfg, "defrost") else None
+    mod.cfg.merge_from_list(["EPIPOLAR_AMD.GENERAL_KERNEL", False])
+    dev = lambda k: torch.from_numpy(d[k]).cuda()
+    f1, f2 = dev("feat1").requires_grad_(True), dev("feat2").requires_grad_(True)
+    assert not mod._general_kernel_applies(f1, f2, None, None)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore", EpipolarSlowPathWarning)
+        kw = _call_kwargs(d, name, dev, depth_grad=True)
+        fin, corr, depth, _ = mod(f1, f2, torch.from_numpy(d["P1"]), torch.from_numpy(d["P2"]), **kw)
+    assert np.abs(depth.detach().cpu().numpy() - d["depth"]).max() <= 1e-5 * max(1.0, float(np.abs(d["depth"]).max()))
+    is_max = "attention_max" in name or "depth_given_max" in name
+    scale = max(1.0, float(np.abs(d["finalout"]).max()))
+    err = np.abs(fin.detach().cpu().numpy() - d["finalout"]).max(1)
+    from epipolar_transformers_amd import ops
+    locs = ops.sample_locs(mod.layer_spec(), torch.from_numpy(d["cam"]).cuda()).cpu().numpy()
+    ties = assert_corr_pos(locs, corr.cpu().numpy(), d["corr_pos"], depth.detach().cpu().numpy(), True, tie=2e-6, max_frac=2e-2)
+    assert (err <= 1e-4 * scale)[~ties].all() if is_max else err.max() <= 1e-4 * scale
+    (fin * dev("grad_out")).sum().backward()
+    if not is_max:        # (ATTENTION max: the tie bookkeeping of the gradients is test_mode_vs_reference's)
+        for got, want in ((f1.grad, d["grad_feat1"]), (f2.grad, d["grad_feat2"])):
+            got = np.zeros_like(want) if got is None else got.cpu().numpy()
+            assert np.abs(got - want).max() <= 1e-4 * max(float(np.abs(want).max()), 1e-6)
+    if "depth_given" in d.files:
+        gd = kw["depth"].grad
+        gd = np.zeros_like(d["grad_depth"]) if gd is None else gd.cpu().numpy()
+        assert np.abs(gd - d["grad_depth"]).max() <= 1e-4 * max(float(np.abs(d["grad_depth"]).max()), 1e-6)
+    _check_prior_grads(mod, d)
 
 
 def test_param_yaml_runs_through_the_backbone():
