@@ -195,7 +195,7 @@ def main():
     if args.rig == "ring":
         P_ref, P_src = syn.make_pairs(frames, V, image, seed=1000 + rank, jitter=(0.05, 8.0))
     else:
-        per_frame = 4 if args.rig == "h36m_room" else 2
+        per_frame = 4 if args.rig in ("h36m_room", "uneven_arc") else 2
         P_ref, P_src = syn.rig_pairs(args.rig, frames * V // per_frame, image, seed=1000 + rank,
                                      jitter=None if args.rig == "epipole_border" else (0.05, 8.0))
     n_pairs = P_ref.shape[0]                                      # frames * views
@@ -203,10 +203,14 @@ def main():
     g = torch.Generator(device=dev).manual_seed(rank)
     if args.partition == "views" and world > 1:
         # rank owns `n_pairs` reference maps of ONE camera (or V/world cameras); sources arrive by all-gather
-        exchange = ViewShardExchange(world, rank, V)
+        # pairing table: the ring neighbour, or -- --rig h36m_room / uneven_arc -- the reference's nearest-camera rule
+        # (vision/multiview.py:59-83): not a permutation in general, the exchange sends a block to every rank that samples it
+        if args.rig not in ("ring", "h36m_room", "uneven_arc"):
+            raise SystemExit("--partition views shards CAMERAS: --rig must be ring, h36m_room or uneven_arc (got %s)" % args.rig)
+        exchange = ViewShardExchange(world, rank, V, source_of=None if args.rig == "ring" else syn.source_table(args.rig))
         # weak scaling: a view group (min(world, V) ranks) shares frames * min(world, V) frames, so every rank
         # still owns frames * V (reference, source) pairs
-        P_ref, P_src = exchange.select_pairs(frames * min(world, V) * V, image, seed=1000)
+        P_ref, P_src = exchange.select_pairs(frames * min(world, V) * V, image, seed=1000, rig=args.rig)
         n_pairs = P_ref.shape[0]
         assert n_pairs == frames * V
     feat_ref = torch.randn(n_pairs, H, W, C, device=dev, generator=g).relu_()      # NHWC, post-ReLU statistics

@@ -5,9 +5,15 @@ Pairs are independent units, so the natural partition is collective-free:
   * frames-DP  -- a rank owns whole frames (all V views local): no exchange.
 The north-star partition shards by camera and has ONE real exchange step:
   * view-sharded -- rank r owns camera(s) v == r (mod G) for its frames; the
-    source map of pair (frame, v) is the map of camera (v+1) mod V of the same
-    frame, produced on another rank, so the per-rank feature maps are
-    all-gathered (RCCL over xGMI) before the fused kernel consumes them.
+    source map of pair (frame, v) is the map of camera source_of[v] of the same
+    frame -- the ring neighbour (v+1) mod V by default, the reference's
+    NEAREST camera in general (vision/multiview.py:59-83 neighbor_cameras +
+    data/datasets/multiview_h36m.py:231-238; `synthetic.source_table`) --,
+    produced on another rank, so the per-rank feature maps are all-gathered
+    (RCCL over xGMI) before the fused kernel consumes them.  The nearest-camera
+    rule is not a permutation: two views may share a source and a view may be
+    nobody's, so the point-to-point form sends a block to EVERY rank that
+    samples it and the backward SUMS what comes back.
 """
 from __future__ import annotations
 
@@ -32,7 +38,12 @@ class ViewShardExchange:
                  frame slice r // V (groups of V ranks exchange among themselves).
     A rank's local pair list is ordered (camera-major, then frame)."""
 
-    def __init__(self, world: int, rank: int, num_views: int, group=None):
+    def __init__(self, world: int, rank: int, num_views: int, group=None, source_of=None):
+        """source_of: the pairing table, source_of[v] = the camera reference camera v samples (default: the ring neighbour;
+        `synthetic.source_table(rig)` / the reference's neighbor_cameras in general -- any map of 0..V-1 into itself)."""
+        self.source_of = [(v + 1) % num_views for v in range(num_views)] if source_of is None else [int(v) for v in source_of]
+        if len(self.source_of) != num_views or any(not 0 <= v < num_views for v in self.source_of):
+            raise ValueError("source_of must name one camera of 0..%d per view, got %r" % (num_views - 1, source_of))
         if world <= num_views:
             if num_views % world:
                 raise ValueError("views (%d) must be a multiple of world size (%d)" % (num_views, world))
@@ -52,13 +63,21 @@ class ViewShardExchange:
         self._own_group = None
 
     # ------------------------------------------------------------------ pairs
-    def select_pairs(self, total_pairs: int, image: int, seed: int):
+    def select_pairs(self, total_pairs: int, image: int, seed: int, rig: str = "ring"):
         """Projection matrices of this rank's pairs.  total_pairs = frames * V of
-        ONE frame slice; every rank regenerates the same rig from `seed`."""
+        ONE frame slice; every rank regenerates the same rig from `seed`.  rig: "ring" (any V) or a four-camera rig of
+        synthetic.rig_cameras, paired by THIS exchange's source_of table."""
         frames = total_pairs // self.V
-        P_ref, P_src = syn.make_pairs(frames, self.V, image, seed=seed + self.slice_id, jitter=(0.05, 8.0))
-        P_ref = P_ref.view(frames, self.V, 3, 4)
-        P_src = P_src.view(frames, self.V, 3, 4)
+        if rig == "ring" and self.source_of == [(v + 1) % self.V for v in range(self.V)]:
+            P_ref, P_src = syn.make_pairs(frames, self.V, image, seed=seed + self.slice_id, jitter=(0.05, 8.0))
+            P_ref = P_ref.view(frames, self.V, 3, 4)
+            P_src = P_src.view(frames, self.V, 3, 4)
+        else:
+            cams = torch.from_numpy(syn.rig_cameras(rig, frames, image, seed=seed + self.slice_id, jitter=(0.05, 8.0))).float()
+            if cams.shape[1] != self.V:
+                raise ValueError("rig %r has %d cameras, the exchange %d" % (rig, cams.shape[1], self.V))
+            P_ref = cams
+            P_src = torch.stack([cams[:, self.source_of[v]] for v in range(self.V)], 1)
         self.frames = frames
         ref = torch.cat([P_ref[:, v] for v in self.my_cams])            # camera-major
         src = torch.cat([P_src[:, v] for v in self.my_cams])
@@ -66,8 +85,8 @@ class ViewShardExchange:
 
     def source_location(self, cam: int):
         """(owner rank, index of that camera in the owner's camera list) of the
-        source view of reference camera `cam` (ring neighbour, multiview_h36m.py:231-238)."""
-        s = (cam + 1) % self.V
+        source view of reference camera `cam` (source_of: multiview_h36m.py:231-238)."""
+        s = self.source_of[cam]
         for r in self.group_ranks:
             if s in self.cams_of[r]:
                 return r, self.cams_of[r].index(s)
@@ -131,8 +150,9 @@ class ViewShardExchange:
             yield ranges, (chunks[0] if len(chunks) == 1 else torch.cat(chunks))
 
     def _routes(self):
-        """The ring pairing as an all-to-all: (send_order, send_split, recv_split, recv_slots) for moving every camera block
-        from the rank that OWNS it to the rank whose reference camera samples it -- each block to exactly one rank.
+        """The pairing as an all-to-all: (send_order, send_split, recv_split, recv_slots) for moving every camera block
+        from the rank that OWNS it to every rank one of whose reference cameras samples it (a block that two views share
+        appears twice in send_order; a block nobody samples not at all).
           send_order : indices into my camera list, grouped by destination rank (group order), inside a destination in the
                        order of ITS reference cameras;   send_split / recv_split: blocks per rank;
           recv_slots : for the blocks as they arrive (source rank major), the index of MY reference camera they belong to."""
@@ -151,7 +171,7 @@ class ViewShardExchange:
     def exchange_sources(self, own_maps: torch.Tensor) -> torch.Tensor:
         """Point-to-point form of gather_sources: ONE all_to_all_single in which every camera block goes only to the rank
         that samples it -- 1 x the bytes a rank consumes, where the all-gather stages G x (at BASELINE config 5, 1 GiB of
-        maps per rank on 8 ranks, 8 GiB to use one).  Same result as gather_sources, bit for bit (a permutation)."""
+        maps per rank on 8 ranks, 8 GiB to use one).  Same result as gather_sources, bit for bit (copies only)."""
         pg = self._pg()
         ncam = len(self.my_cams)
         f = own_maps.shape[0] // ncam
@@ -205,10 +225,12 @@ class ViewShardExchange:
                 yield ranges, torch.cat(blocks)
 
     def scatter_source_grads(self, grad_src: torch.Tensor) -> torch.Tensor:
-        """Backward of gather_sources: route d(source maps) back to the ranks that own those maps.  Every map is
-        the source of exactly ONE reference camera (ring pairing), so this is a permutation, not a reduction: one
+        """Backward of gather_sources: route d(source maps) back to the ranks that own those maps: one
         all_to_all_single in which a rank sends each camera's gradient block to its owner only -- 1x the data, where
-        an all-gather (or a reduce-scatter over zero-padded slots) would move G x."""
+        an all-gather (or a reduce-scatter over zero-padded slots) would move G x.  With the ring pairing every map is
+        the source of exactly one reference camera and this is a permutation; with the nearest-camera rule a map may be
+        sampled by several views (their blocks are SUMMED, in arrival order = group-rank order, then camera order: fixed,
+        so the sum is reproducible) or by none (zeros)."""
         pg = self._pg()
         ncam = len(self.my_cams)
         f = grad_src.shape[0] // ncam
@@ -242,7 +264,7 @@ class ViewShardExchange:
 class _ShardedSources(torch.autograd.Function):
     """own maps (this rank's cameras, camera-major) -> the source maps of this rank's pairs.  Forward: ONE all-gather
     over the view group (`gather_sources`); backward: ONE all-to-all that returns d(source maps) to the ranks that own
-    those maps (`scatter_source_grads`: a permutation, every map is the source of exactly one reference camera)."""
+    those maps (`scatter_source_grads`: summed where several views sample one map)."""
 
     @staticmethod
     def forward(ctx, own_maps, exchange, p2p=False):

@@ -117,11 +117,53 @@ def nearest_neighbour_pairs(mats):
     return src
 
 
+# four cameras on an uneven arc: nearest neighbours that are NOT mutual -- cameras 0 and 2 both take camera 1 as their source,
+# camera 3 is nobody's -- what the reference's pairing rule gives for a rig like this and a ring pairing cannot express
+_UNEVEN_ARC_ANGLES = (0.10, 0.55, 1.25, 2.60)
+
+
+def rig_cameras(rig, num_frames=1, image_size=256, seed=0, jitter=None):
+    """The cameras themselves, (num_frames, V, 3, 4) float64, of a rig whose views can be sharded one camera per rank:
+    "ring" (as make_pairs draws them), "h36m_room" (as rig_pairs draws them: the same matrices for the same seed) and
+    "uneven_arc" (four cameras whose nearest neighbours are not mutual).  Pair them with source_table(rig)."""
+    rng = np.random.default_rng(seed)
+    target = np.array([0.0, 0.0, 900.0])
+    out = []
+    for _ in range(num_frames):
+        if rig == "ring":
+            cams = ring_cameras(4, image_size, jitter=jitter, rng=rng)
+        elif rig == "h36m_room":
+            cams = [_projection(*look_at_camera(c, target + rng.normal(0, 50.0, 3)), image_size, jitter=jitter, rng=rng)
+                    for c in _H36M_ROOM_CENTRES]
+        elif rig == "uneven_arc":
+            cams = [_projection(*look_at_camera(np.array([5000.0 * math.cos(a), 5000.0 * math.sin(a), 1500.0]), target), image_size,
+                                jitter=jitter, rng=rng) for a in _UNEVEN_ARC_ANGLES]
+        else:
+            raise ValueError("rig_cameras: no multi-camera rig named %r" % (rig,))
+        out.append(np.stack(cams))
+    return np.stack(out)
+
+
+def source_table(rig, num_views=4):
+    """source_of[v] = the camera whose map reference camera v samples: the ring neighbour for "ring" (make_pairs), the
+    reference's nearest-neighbour rule (nearest_neighbour_pairs: vision/multiview.py:59-83 + multiview_h36m.py:231-238) for the
+    rigs with fixed camera centres.  Not a permutation in general: two views may share a source, a view may be nobody's."""
+    if rig == "ring":
+        return [(v + 1) % num_views for v in range(num_views)]
+    return nearest_neighbour_pairs(list(rig_cameras(rig, 1, 256, seed=0)[0]))
+
+
 def rig_pairs(rig, num_frames=1, image_size=256, seed=0, jitter=None):
     """P_ref, P_src (N,3,4) float32 of a named rig (RIGS); N = 4 * num_frames except for the two-camera rigs, which
     yield both orderings of the pair per frame (N = 2 * num_frames)."""
     if rig == "ring":
         return make_pairs(num_frames, 4, image_size, seed, jitter)
+    if rig == "uneven_arc":         # (not in RIGS: a pairing-table case of the view-sharded exchange, not a geometry case)
+        cams = rig_cameras(rig, num_frames, image_size, seed, jitter)
+        table = source_table(rig)
+        ref = torch.from_numpy(cams.reshape(-1, 3, 4)).float()
+        src = torch.from_numpy(np.stack([cams[f, table[v]] for f in range(num_frames) for v in range(4)])).float()
+        return ref, src
     rng = np.random.default_rng(seed)
     target = np.array([0.0, 0.0, 900.0])
     p_ref, p_src = [], []

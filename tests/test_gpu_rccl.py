@@ -118,8 +118,11 @@ def test_view_shard_exchange_runs_on_rccl_with_one_rank():
     assert proc.returncode == 0 and "rccl-1rank ok" in proc.stdout, proc.stdout[-4000:]
 
 
-@pytest.mark.parametrize("world,p2p", [(4, False), (4, True), (2, True), (8, False)], ids=["4ranks-allgather", "4ranks-p2p", "2ranks-p2p", "8ranks-allgather"])
-def test_bench_view_partition_with_several_ranks_on_one_gpu(tmp_path, world, p2p):
+@pytest.mark.parametrize("world,p2p,rig", [(4, False, "ring"), (4, True, "ring"), (2, True, "ring"), (8, False, "ring"),
+                                           (4, True, "h36m_room"), (4, True, "uneven_arc"), (2, False, "uneven_arc")],
+                         ids=["4ranks-allgather", "4ranks-p2p", "2ranks-p2p", "8ranks-allgather", "4ranks-p2p-room-rig",
+                              "4ranks-p2p-shared-source", "2ranks-allgather-shared-source"])
+def test_bench_view_partition_with_several_ranks_on_one_gpu(tmp_path, world, p2p, rig):
     """`bench.py --gpus N --partition views` with N processes on cuda:0 (BENCH_SINGLE_DEVICE=1, gloo instead of RCCL: a 1-GPU
     box has no second device): `layer_step_view_sharded`, `select_pairs`, the chunked exchange (all-gather and point-to-point)
     and its range bookkeeping with world > 1 on DEVICE tensors.  Every rank dumps its maps, matrices and the x of one step;
@@ -134,7 +137,7 @@ def test_bench_view_partition_with_several_ranks_on_one_gpu(tmp_path, world, p2p
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--partition", "views",
            "--steps", "2", "--warmup", "1", "--frames", str(frames), "--hw", str(hw), "--samples", "16", "--exchange-chunks", "2",
-           "--no-cpu-baseline", "--no-end-to-end", "--no-other-configs"] + (["--p2p"] if p2p else [])
+           "--no-cpu-baseline", "--no-end-to-end", "--no-other-configs", "--rig", rig] + (["--p2p"] if p2p else [])
     proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900, cwd=ROOT)
     assert proc.returncode == 0, proc.stdout[-4000:]
     line = [l for l in proc.stdout.splitlines() if l.startswith("{")][-1]
@@ -142,14 +145,17 @@ def test_bench_view_partition_with_several_ranks_on_one_gpu(tmp_path, world, p2p
     assert res["n_gpus"] == world and res["config"]["partition"] == "views" and res["value"] > 0
     assert ("all_to_all" in res["config"]["exchange"]) == p2p
 
-    from epipolar_transformers_amd import camera, ops
+    from epipolar_transformers_amd import camera, ops, synthetic as syn
     from epipolar_transformers_amd.parallel import ViewShardExchange
 
+    # (the pairing table: the ring neighbour, or the reference's nearest-camera rule -- room rig [2, 3, 0, 1], uneven arc
+    #  [1, 0, 1, 2]: two views share a source, one camera is nobody's)
+    table = None if rig == "ring" else syn.source_table(rig)
     dumps = [torch.load(os.path.join(str(tmp_path), "rank%d.pt" % r)) for r in range(world)]
     spec = ops.LayerSpec(H=hw, W=hw, K=16)
     n = frames * V
     for r, d in enumerate(dumps):
-        ex = ViewShardExchange(world, r, V)
+        ex = ViewShardExchange(world, r, V, source_of=table)
         assert d["my_cams"] == ex.my_cams and d["x"].shape[0] == n
         f = n // len(ex.my_cams)
         src = torch.empty_like(d["feat"])

@@ -108,6 +108,91 @@ def test_view_sharded_exchange_gloo(world, V):
     assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
 
 
+def _worker_table(rank, world, port, rig, frames, errs):
+    """The exchange under a pairing table that is not the ring: the room rig's nearest-neighbour table [2, 3, 0, 1] and the
+    uneven arc's [1, 0, 1, 2] (cameras 0 and 2 share a source, camera 3 is nobody's) -- against what ONE process computes
+    from the same maps: forward bit for bit, the summed gradient to 1e-6."""
+    try:
+        from epipolar_transformers_amd import synthetic as syn
+        from epipolar_transformers_amd.parallel import sharded_sources
+
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        V = 4
+        table = syn.source_table(rig)
+        ex = ViewShardExchange(world, rank, V, source_of=table)
+        P_ref, P_src = ex.select_pairs(frames * V, 64, seed=3, rig=rig)
+        # the single-process view of the same batch: every map of every (frame, camera), random, the same on every rank
+        g = torch.Generator().manual_seed(1234)
+        maps = torch.randn(frames, V, 2, 3, 4, generator=g)
+        wgt = torch.randn(frames, V, 2, 3, 4, generator=g)
+        layer = lambda ref, src: ref * src + 0.5 * src * src            # a differentiable stand-in for the layer
+        full = maps.clone().requires_grad_(True)
+        src_full = torch.stack([full[:, table[v]] for v in range(V)], 1)             # (frames, V, ...): source map of pair (f, v)
+        out_full = layer(full, src_full)
+        (out_full * wgt).sum().backward()
+        # this rank's share, camera-major
+        own = torch.cat([maps[:, v] for v in ex.my_cams])
+        want_src = torch.cat([maps[:, table[v]] for v in ex.my_cams])
+        assert torch.equal(ex.gather_sources(own), want_src)
+        assert torch.equal(ex.exchange_sources(own), want_src)
+        for fn in (ex.gather_sources_chunked, ex.exchange_sources_chunked):
+            got = torch.full_like(want_src, float("nan"))
+            for ranges, m in fn(own, 2):
+                off = 0
+                for a, b in ranges:
+                    got[a:b] = m[off:off + (b - a)]
+                    off += b - a
+            assert torch.equal(got, want_src), fn.__name__
+        # the projection matrices follow the table
+        cams = torch.from_numpy(syn.rig_cameras(rig, frames, 64, seed=3, jitter=(0.05, 8.0))).float()
+        assert torch.equal(P_ref, torch.cat([cams[:, v] for v in ex.my_cams]))
+        assert torch.equal(P_src, torch.cat([cams[:, table[v]] for v in ex.my_cams]))
+        if rig == "h36m_room":      # ... and are the pairs the single-process rig generator makes (frame-major there)
+            r1, r2 = syn.rig_pairs(rig, frames, 64, seed=3, jitter=(0.05, 8.0))
+            assert torch.equal(P_src, torch.cat([r2.view(frames, V, 3, 4)[:, v] for v in ex.my_cams]))
+        for p2p in (False, True):
+            for chunks in (1, 2):
+                a = own.clone().requires_grad_(True)
+                src = sharded_sources(a, ex, num_chunks=chunks, p2p=p2p)
+                out = layer(a, src)
+                want_out = torch.cat([out_full[:, v] for v in ex.my_cams]).detach()
+                assert torch.equal(out, want_out), "forward differs from the single process (p2p=%s, chunks=%d)" % (p2p, chunks)
+                (out * torch.cat([wgt[:, v] for v in ex.my_cams])).sum().backward()
+                want_g = torch.cat([full.grad[:, v] for v in ex.my_cams])
+                err = (a.grad - want_g).abs().max().item()
+                assert err <= 1e-6 * max(1.0, want_g.abs().max().item()), (err, p2p, chunks)
+        # a camera nobody samples gets exactly zero from the exchange's backward
+        back = ex.scatter_source_grads(torch.ones_like(own))
+        for ci, c in enumerate(ex.my_cams):
+            assert torch.equal(back[ci * frames:(ci + 1) * frames], torch.full_like(back[:frames], float(table.count(c))))
+        dist.barrier()
+        dist.destroy_process_group()
+    except Exception as exc:  # pragma: no cover - surfaced in the parent
+        errs.put("rank %d: %r" % (rank, exc))
+        raise
+
+
+@pytest.mark.parametrize("world,rig", [(4, "h36m_room"), (4, "uneven_arc"), (2, "uneven_arc"), (2, "h36m_room")])
+def test_view_sharded_exchange_with_the_reference_pairing(world, rig):
+    """the view-sharded exchange under the reference's nearest-camera pairing (a table, not the ring)."""
+    from epipolar_transformers_amd import synthetic as syn
+    assert syn.source_table("h36m_room") == [2, 3, 0, 1] and syn.source_table("uneven_arc") == [1, 0, 1, 2]
+    ctx = mp.get_context("spawn")
+    errs = ctx.SimpleQueue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_table, args=(r, world, port, rig, 3, errs)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(180)
+    msgs = []
+    while not errs.empty():
+        msgs.append(errs.get())
+    assert not msgs, msgs
+    assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+
+
 def test_view_sharded_layout_world8_views4():
     # two ranks per camera: groups of 4 ranks exchange among themselves
     for rank in range(8):
