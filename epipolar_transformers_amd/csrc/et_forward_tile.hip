@@ -144,7 +144,8 @@ int et_epipolar_forward_tiled(const EtLayerDesc *desc, const float *xs, const fl
     const size_t lds = (size_t)(fwd_tile_array_floats(rows) + rows + kTilePix + 48 + kTilePix * 4) * 4 +
                        (size_t)tp.hw_words * 8 + (kpl == 1 ? (size_t)kTilePix * kWave * 8 : 0);
 #define ET_SET_LDS(KERNEL, BYTES) ET_GRANT_LDS(KERNEL, BYTES, dev)
-    if (tile_ws_eligible(desc)) {
+    const bool two_pass = tile_ws_two_pass(desc);
+    if (tile_ws_eligible(desc) || two_pass) {
         // 2a. the persistent, warp-specialised kernel (kernels_forward_tile_ws.inc): the default ...
         TileWsParams wp;
         wp.f = p;
@@ -172,7 +173,13 @@ int et_epipolar_forward_tiled(const EtLayerDesc *desc, const float *xs, const fl
 #endif
         const int cus = device_cus(dev);
         const unsigned grid = (unsigned)(total < cus ? total : cus);
-        if (tile_ws_band(desc)) {       // maps above 64 x 64 (up to 96 x 96): 288-row arrays, slot table over the tile's band
+        if (two_pass) {                 // 64 < K <= 128: two passes of 64 samples per tile, online soft-max (maps up to 128 x 128)
+            if (wp.rows_cap > kTileRowsWsLarge) wp.rows_cap = kTileRowsWsLarge;
+            const size_t lds_ws = tile_ws_lds_bytes(kTileRowsWsLarge, desc->H, desc->W, true);
+            ET_SET_LDS((epipolar_fwd_tile_ws_kernel<kTileRowsWsLarge, 8, false, true, 2>), lds_ws);
+            hipLaunchKernelGGL((epipolar_fwd_tile_ws_kernel<kTileRowsWsLarge, 8, false, true, 2>), dim3(grid),
+                               dim3((kWsMatrixWaves + 8) * kWave), lds_ws, st, wp);
+        } else if (tile_ws_band(desc)) {       // maps above 64 x 64 (up to 96 x 96): 288-row arrays, slot table over the tile's band
             if (wp.rows_cap > kTileRowsWsLarge) wp.rows_cap = kTileRowsWsLarge;
             const size_t lds_ws = tile_ws_lds_bytes(kTileRowsWsLarge, desc->H, desc->W, true);
             ET_SET_LDS((epipolar_fwd_tile_ws_kernel<kTileRowsWsLarge, 8, false, true>), lds_ws);
@@ -187,13 +194,21 @@ int et_epipolar_forward_tiled(const EtLayerDesc *desc, const float *xs, const fl
         if (int e = check_launch("et_epipolar_forward_tiled(ws)")) return e;
         // ... 2b. and the tiles it left over one block per tile
         const unsigned lgrid = (unsigned)(total < 2LL * cus ? total : 2LL * cus);
-        if (rows == kTileRowsLarge) {
-            ET_SET_LDS((epipolar_fwd_tile_list_kernel<1, kTileRowsLarge>), lds);
-            hipLaunchKernelGGL((epipolar_fwd_tile_list_kernel<1, kTileRowsLarge>), dim3(lgrid), dim3(256), lds, st, tp);
+#define ET_LIST(KK, RR)                                                                                                 \
+    do {                                                                                                                \
+        ET_SET_LDS((epipolar_fwd_tile_list_kernel<KK, RR>), lds);                                                       \
+        hipLaunchKernelGGL((epipolar_fwd_tile_list_kernel<KK, RR>), dim3(lgrid), dim3(256), lds, st, tp);               \
+    } while (0)
+        if (kpl == 2) {                 // (the two-pass kernel's left-overs: whole tiles, all K samples, one block per tile)
+            if (rows == kTileRowsHuge) ET_LIST(2, kTileRowsHuge);
+            else if (rows == kTileRowsLarge) ET_LIST(2, kTileRowsLarge);
+            else ET_LIST(2, kTileRowsSmall);
+        } else if (rows == kTileRowsLarge) {
+            ET_LIST(1, kTileRowsLarge);
         } else {
-            ET_SET_LDS((epipolar_fwd_tile_list_kernel<1, kTileRowsSmall>), lds);
-            hipLaunchKernelGGL((epipolar_fwd_tile_list_kernel<1, kTileRowsSmall>), dim3(lgrid), dim3(256), lds, st, tp);
+            ET_LIST(1, kTileRowsSmall);
         }
+#undef ET_LIST
         return check_launch("et_epipolar_forward_tiled(list)");
     }
     // 2. one block per tile

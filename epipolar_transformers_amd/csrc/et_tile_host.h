@@ -43,6 +43,14 @@ bool tile_ws_band(const EtLayerDesc *d)
         return false;
     return tile_rows(d) == kTileRowsLarge || ((d->variant & ET_VARIANT_WS_BAND) && tile_rows(d) == kTileRowsSmall);
 }
+// 64 < K <= 128 (round 6): the band-table instance in TWO passes of 64 samples per tile with an online soft-max
+// (kernels_forward_tile_ws.inc, KH = 2), maps up to 128 x 128 (its column masks hold 128 columns).  Sample + attention only: the
+// one-kernel layer keeps K <= 64.
+bool tile_ws_two_pass(const EtLayerDesc *d)
+{
+    const int longest = d->W > d->H ? d->W : d->H;
+    return !(d->variant & ET_VARIANT_TILE_CLASSIC) && d->softmax_enabled && d->K > 64 && d->K <= 128 && d->W >= 2 && longest <= kWsMaxSideTwoPass;
+}
 bool tile_ws_eligible(const EtLayerDesc *d)
 {
     return (!(d->variant & ET_VARIANT_TILE_CLASSIC) && d->softmax_enabled && d->K <= 64 && d->W >= 2 &&
