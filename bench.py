@@ -724,10 +724,12 @@ def other_config(dev, hw, samples, views, frames, name, C=256):
     kpl = (samples + 63) // 64
     rows = 256 if hw <= 64 else (512 if 4 * min(samples, hw) > 384 else 384)
     persistent = samples <= 64 and hw <= 96           # (et_tile_host.h: tile_ws_eligible)
+    two_pass = 64 < samples <= 128 and hw <= 128      # (tile_ws_two_pass: two passes of 64 samples per tile, online soft-max)
     ws_name = "epipolar_fwd_tile_ws_kernel<" + ws_instance(hw, hw, "%s") + ">"
     return {"workload": name, "pairs": n, "forward_ms": f_ms, "forward_frac_of_hbm_peak": fb / (f_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
             "forward_pair_views_per_s": n / (f_ms * 1e-3),
-            "forward_kernel": (ws_name % "false" if persistent else "epipolar_fwd_tile_kernel<%d, %d>" % (kpl, rows)) +
+            "forward_kernel": (ws_name % "false" if persistent else "epipolar_fwd_tile_ws_kernel<288, 8, false, true, 2> (two 64-sample passes per tile)"
+                               if two_pass else "epipolar_fwd_tile_kernel<%d, %d>" % (kpl, rows)) +
                               " (+ tile_keys_kernel, tile_order_kernel)",
             "layer_ms": l_ms, "layer_pair_views_per_s": n / (l_ms * 1e-3),
             "layer_kernels": (ws_name % "true") if one_kernel else "the forward kernel + residual_gemm_kernel",
