@@ -63,6 +63,15 @@ bool tile_ws_eligible(const EtLayerDesc *d)
 //   segments[tiles * 32] (float4, 16-byte aligned; in tile order.  Until tile_order_kernel writes them the region of a pair
 //   holds the pair's sort keys: 8 bytes per pixel, tile_keys_kernel) |
 //   band[tiles] (float4: the tile's base line, warp-specialised kernel) | segments by pixel[N * HW] (float4)
+// Header words beyond [0] / [1] are scratch of the kernels of ONE call, cleared by tile_keys_kernel (`header`) at its start:
+//   forward:  [2 .. 9]  one tile counter per XCD (the blocks of an XCD draw their tiles from it)
+//   backward: [2] four-group tiles met so far, [3] eight-or-more-group tiles met early (kernels_backward_tile.inc: the merged
+//             kernel splits the first 128 / 32 of a call in place and defers the rest to its second launch)
+// The backward REUSES the forward's counter words: safe because every call starts with the ordering kernels on the same stream,
+// which zero them -- a change to either user has to keep that.  Which over-capacity tiles a backward call splits in
+// place and which it defers depends on the order its blocks reach those counters and on blockIdx relative to gridDim: the
+// SET of deferred tiles, and with it the order of the float-atomic additions into grad_src, differs from run to run
+// (gradients reproducible to rounding, as documented; ops.backward_deferred_tiles() counts vary by a few tiles).
 struct TileWorkspace {
     int *perm, *ovf_count, *err, *ovf_list, *stats;
     float *scales;
