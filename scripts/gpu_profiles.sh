@@ -42,7 +42,7 @@ stats config5 --steps 5 --warmup 2 --no-cpu-baseline --samples 128 --hw 128 --fr
 # AverageNs in these files is the time of that shape (the stats of a whole bench run mix the call sizes of every config it times)
 shape_stats() {  # shape_stats NAME  (PROF_* in the environment)
   local name=$1
-  (cd /tmp && export TMPDIR=/tmp && PROF_REPS=10 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_${TAG}_$name" -o trace -- \
+  (cd /tmp && export TMPDIR=/tmp && PROF_REPS=60 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_${TAG}_$name" -o trace -- \
       python "$ROOT/scripts/profile_kernel.py" > "$OUT/${TAG}_${name}_rocprof.log" 2>&1)
   local f=$(find "$OUT/prof_${TAG}_$name" -name "*kernel_stats.csv" | head -1)
   [ -n "$f" ] && cp "$f" "$OUT/${TAG}_shape_${name}_kernel_stats.csv" && head -4 "$f"
