@@ -318,3 +318,6 @@ def build_backbone(cfg=None):
     """modeling/backbones/backbone.py:9-13."""
     cfg = cfg if cfg is not None else get_cfg()
     return BACKBONES[cfg.BACKBONE.BODY](cfg)
+
+
+from . import hourglass  # noqa: E402,F401  (registers HG* / epipolarHG* / simplemultiviewHG*: modeling/backbones/ProHG.py:319-395)

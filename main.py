@@ -40,6 +40,12 @@ def install(reference_root=REFERENCE_ROOT):
     import modeling.backbones.resnet as ref_resnet       # reference module; its PoseResNet builds `Epipolar()`
 
     ref_resnet.Epipolar = Epipolar
+    try:                                                 # ... and its hourglass nets (modeling/backbones/ProHG.py:182-183)
+        import modeling.backbones.ProHG as ref_hg
+
+        ref_hg.Epipolar = Epipolar
+    except Exception:                                    # (a reference tree without the hourglass module)
+        pass
     _keep_host_matrices(Epipolar)
     return ref_cfg
 
