@@ -437,6 +437,8 @@ def main():
     split = tiled and not (args.variant & _lib.ET_VARIANT_TILE_EXACT)
     # (the persistent kernel's predicate, et_tile_host.h tile_ws_eligible: K <= 64, maps up to 96 x 96, soft-max on, no CLASSIC bit)
     ws = split and not (args.variant & _lib.ET_VARIANT_TILE_CLASSIC) and K <= 64 and 2 <= W and max(H, W) <= 96
+    # (tile_ws_two_pass: 64 < K <= 128 on maps up to 128 x 128 -- the band instance in two 64-sample passes per tile)
+    ws2 = split and not (args.variant & _lib.ET_VARIANT_TILE_CLASSIC) and 64 < K <= 128 and 2 <= W and max(H, W) <= 128
     traffic = measured_hbm_traffic(C, H, W, K, n_pairs, one_kernel)
     traffic_src = "profiles/%s (rocprofv3 --pmc pass, committed)" % ("fwd_fused_pmc_latest.json" if one_kernel else "fwd_pmc_latest.json")
     # (an algorithmic RATE, not a fraction of a peak: the products run on the fp16 matrix cores, three MFMAs per fp32 product)
@@ -449,7 +451,9 @@ def main():
                 "algorithmic_bytes_per_launch": bytes_launch, "kernel_ms": kernel_ms, "kernel_ms_min": k_ms[0],
                 "kernel": ("epipolar_fwd_tile_ws_kernel<%s>: sampling + attention + the z / BN / residual GEMM (et_epipolar_forward_fused)"
                            % ws_instance(H, W, True) if one_kernel
-                           else "epipolar_fwd_tile_ws_kernel<%s>" % ws_instance(H, W, False) if ws else "epipolar_fwd_tile_kernel" if tiled
+                           else "epipolar_fwd_tile_ws_kernel<%s>" % ws_instance(H, W, False) if ws
+                           else "epipolar_fwd_tile_ws_kernel<288, 8, false, true, 2> (two 64-sample passes per tile)" if ws2
+                           else "epipolar_fwd_tile_kernel" if tiled
                            else "epipolar_fwd_kernel") + " (+ tile_keys_kernel, tile_order_kernel)" * bool(tiled),
                 "algorithmic_flop_rate": flop}
     if one_kernel:
