@@ -321,13 +321,17 @@ def main():
                 fused_layer(feat_ref, feat_src, cam_dev, fwd_ws)
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
+        copy_outside = os.environ.get("BENCH_GRAPH_COPY_OUTSIDE", "0") == "1"     # (development: the copy node's share)
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph):
-            cam_dev.copy_(cam_host, non_blocking=True)
+            if not copy_outside:
+                cam_dev.copy_(cam_host, non_blocking=True)
             graph_out = fused_layer(feat_ref, feat_src, cam_dev, fwd_ws)
 
         def layer_step():                                        # noqa: F811
             cam_host.copy_(camera.pair_algebra(P_ref_pin, P_src_pin))
+            if copy_outside:
+                cam_dev.copy_(cam_host, non_blocking=True)
             graph.replay()
             return graph_out
 

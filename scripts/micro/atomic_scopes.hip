@@ -4,6 +4,7 @@
 // build: hipcc --offload-arch=gfx950 -O3 -o atomic_scopes atomic_scopes.hip
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <cstdlib>
 #include <vector>
 typedef __attribute__((address_space(8))) void *rsrc_t;
 
@@ -26,6 +27,20 @@ __global__ __launch_bounds__(256) void k(float *dst, unsigned rows, int iters)
         else if (MODE == 4) __hip_atomic_fetch_add(p, 1.0f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
         else if (MODE == 5) __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(1.0f, buf, (int)off, 0, 16);   // aux bit 4: sc1
         else if (MODE == 6) { float v = *p; *p = v + 1.0f; }      // (plain read-modify-write: WRONG sums, the rate of the traffic alone)
+        // 64-bit operands: is the rate one OPERATION or one dword per clock and channel?  (lane -> 8 bytes: a half-wave covers
+        // 256 bytes of the row; the sum check counts the low dword only)
+        else if (MODE == 7) {
+            unsigned long long *q = (unsigned long long *)(dst + (row * 1024u + (unsigned)((i & 3) * 64 + li * 2) * 4u) / 4);
+            __hip_atomic_fetch_add(q, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else if (MODE == 8) {
+            double *q = (double *)(dst + (row * 1024u + (unsigned)((i & 3) * 64 + li * 2) * 4u) / 4);
+            __hip_atomic_fetch_add(q, 1.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else if (MODE == 9) {   // one 256-byte run per wave instead of two 128-byte runs
+            const unsigned row1 = (state >> 8) % rows;
+            __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(1.0f, buf, (int)(row1 * 1024u + (unsigned)((i & 3) * 64 + lane) * 4u), 0, 0);
+        } else if (MODE == 10) {  // integer add, 32 bit
+            __hip_atomic_fetch_add((unsigned *)p, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
     }
 }
 
@@ -49,13 +64,19 @@ void run(const char *name, float *dst, unsigned rows, int blocks, int iters)
     for (float v : h) sum += v;
     const double want = 4.0 * blocks * 4.0 * iters * 64.0;
     const double n = (double)blocks * 4 * iters;
+    const double bytes = (MODE == 7 || MODE == 8) ? 512 : 256;
+    if (MODE >= 7 && MODE != 9) {
+        printf("%-44s %.3f ms  %.2f G wave-instr/s  %.0f GB/s\n", name, best, n / best / 1e6, n * bytes / best / 1e6);
+        return;
+    }
     printf("%-44s %.3f ms  %.2f G wave-instr/s  %.0f GB/s   sum %.0f of %.0f %s\n", name, best, n / best / 1e6, n * 256 / best / 1e6, sum, want,
            sum == want ? "(exact)" : "(LOST UPDATES)");
 }
 
-int main()
+int main(int argc, char **argv)
 {
-    const unsigned rows = 1u << 18;
+    const unsigned rows = argc > 1 ? (unsigned)atoi(argv[1]) : 1u << 18;      // (1 KB each; default 256 MB)
+    printf("array: %u rows of 1 KB = %.1f MB\n", rows, rows / 1024.0);
     float *dst; hipMalloc(&dst, (size_t)rows * 1024);
     const int blocks = 2048, iters = 256;
     run<0>("buffer_atomic_fadd aux 0 (the backward's)", dst, rows, blocks, iters);
@@ -65,5 +86,9 @@ int main()
     run<2>("__hip_atomic_fetch_add agent scope", dst, rows, blocks, iters);
     run<3>("__hip_atomic_fetch_add system scope", dst, rows, blocks, iters);
     run<6>("plain load + store (no atomic)", dst, rows, blocks, iters);
+    run<9>("buffer_atomic_fadd, one 256-byte run / wave", dst, rows, blocks, iters);
+    run<10>("atomic add u32 agent scope", dst, rows, blocks, iters);
+    run<7>("atomic add u64 agent scope (8 B / lane)", dst, rows, blocks, iters);
+    run<8>("atomic add f64 agent scope (8 B / lane)", dst, rows, blocks, iters);
     return 0;
 }
