@@ -781,9 +781,31 @@ def end_to_end(dev, hw, samples, channels, frames, V, body="epipolarposeR-50"):
         step()
     torch.cuda.synchronize()
     ms = (time.perf_counter() - t0) / reps * 1e3
-    return {"ms_per_step": ms, "views_per_s": n / (ms * 1e-3), "views": n, "image": hw * 4,
-            "model": "%s random init, fp32, eval" % body,
-            "note": "trunk once per view (the reference runs it twice per pair)"}
+    res = {"ms_per_step": ms, "views_per_s": n / (ms * 1e-3), "views": n, "image": hw * 4,
+           "model": "%s random init, fp32, eval" % body,
+           "note": "trunk once per view (the reference runs it twice per pair)"}
+    # The same step with the stock trunk under autocast (EPIPOLAR_AMD.TRUNK_DTYPE; the layer stays fp32): an OPTION, not the
+    # reference's arithmetic -- reported with what it does to the detections of the very same images and weights.
+    locs32 = step()[2].float()
+    for dt in ("bf16", "fp16"):
+        try:
+            cfg.merge_from_list(["EPIPOLAR_AMD.TRUNK_DTYPE", dt])
+            for _ in range(3):
+                step()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                step()
+            torch.cuda.synchronize()
+            ms_r = (time.perf_counter() - t0) / reps * 1e3
+            dev_px = (step()[2].float() - locs32).norm(dim=-1)
+            res["trunk_" + dt] = {"ms_per_step": ms_r, "views_per_s": n / (ms_r * 1e-3),
+                                  "detections_vs_fp32_trunk_px": {"mean": float(dev_px.mean()), "max": float(dev_px.max())}}
+        except Exception as exc:                                  # (an option: never fatal for the line)
+            res["trunk_" + dt] = {"error": "%s: %s" % (type(exc).__name__, exc)}
+        finally:
+            cfg.merge_from_list(["EPIPOLAR_AMD.TRUNK_DTYPE", "fp32"])
+    return res
 
 
 def mpjpe_delta(dev):

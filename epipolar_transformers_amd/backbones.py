@@ -21,7 +21,7 @@ import torch
 from torch import nn
 import torch.nn.functional as F
 
-from .config import get_cfg
+from .config import amd_knob, get_cfg
 from .epipolar import Epipolar
 
 
@@ -198,6 +198,16 @@ class PoseResNet(nn.Module):
         suspicion that MIOpen leaves its tuned fp32 solvers there: it does not, one pass is 4 % faster, scripts/e2e_shapes.py.)"""
         if x.is_cuda:
             x = x.contiguous(memory_format=torch.channels_last)             # NHWC all the way to the fused kernel
+        dt = str(amd_knob(self.cfg, "TRUNK_DTYPE", "fp32"))
+        if dt != "fp32":
+            # the stock convolutions in reduced precision (an option: NOT the reference's arithmetic; bench.py reports what it does
+            # to the detections); the fused layer takes fp32 maps, channels_last as they come
+            if dt not in ("bf16", "fp16"):
+                raise ValueError("EPIPOLAR_AMD.TRUNK_DTYPE must be fp32, bf16 or fp16, not %r" % (dt,))
+            with torch.autocast(x.device.type, dtype=torch.bfloat16 if dt == "bf16" else torch.float16):
+                x = self.layer1(self.maxpool(self.relu(self.bn1(self.conv1(x)))))
+                x = self.deconv_layers(self.layer4(self.layer3(self.layer2(x))))
+            return x.float()
         x = self.layer1(self.maxpool(self.relu(self.bn1(self.conv1(x)))))
         return self.deconv_layers(self.layer4(self.layer3(self.layer2(x))))
 

@@ -185,6 +185,8 @@ def default_cfg() -> CfgNode:
     C.EPIPOLAR_AMD.FUSED_EPILOGUE = True      # eval: fold BN and fuse the residual adds in one kernel
     C.EPIPOLAR_AMD.SHARD_P2P = False          # view-sharded partition: source maps by one all-to-all (each block to the rank that
                                               # samples it) instead of the all-gather BASELINE.json's north star names (G x the bytes)
+    C.EPIPOLAR_AMD.TRUNK_DTYPE = "fp32"       # arithmetic of the stock trunk (convolutions of `PoseResNet.trunk`): fp32 (the reference's)
+                                              # | bf16 | fp16 = torch.autocast around it; the epipolar layer stays fp32 either way
     return C
 
 

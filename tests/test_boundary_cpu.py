@@ -60,6 +60,24 @@ def test_single_view_forward_shapes_cpu():
     assert tuple(locs.shape) == (2, 17, 2) and tuple(scos.shape) == (2, 17) and corr is None and depth is None
 
 
+def test_trunk_dtype_knob_cpu():
+    """EPIPOLAR_AMD.TRUNK_DTYPE: fp32 is the default and the reference's arithmetic; bf16 runs the stock convolutions under autocast
+    and still hands the layer an fp32 map; anything else is refused."""
+    cfg = _cfg()
+    assert cfg.EPIPOLAR_AMD.TRUNK_DTYPE == "fp32"
+    net = backbones.build_backbone(cfg).eval()
+    x = torch.randn(2, 3, 64, 64)
+    with torch.no_grad():
+        full = net.trunk(x)
+        cfg.merge_from_list(["EPIPOLAR_AMD.TRUNK_DTYPE", "bf16"])
+        low = net.trunk(x)
+        cfg.merge_from_list(["EPIPOLAR_AMD.TRUNK_DTYPE", "int8"])
+        with pytest.raises(ValueError):
+            net.trunk(x)
+    assert low.dtype == torch.float32 and low.shape == full.shape
+    assert 0 < (low - full).abs().max().item() <= 0.1 * full.abs().max().item()
+
+
 @needs_ref
 def test_checkpoint_keys_and_single_view_parity_with_reference(tmp_path):
     from oracle import ref_harness as rh

@@ -67,6 +67,29 @@ def test_trunk_once_per_view_equals_the_two_pass_reference_form():
     assert m.reference.conv1.weight.grad is not None and m.reference.epipolar_sampler.z.weight.grad is not None
 
 
+@pytest.mark.parametrize("dt", ["bf16", "fp16"])
+def test_reduced_precision_trunk_option(dt):
+    """EPIPOLAR_AMD.TRUNK_DTYPE: the stock trunk under autocast, the fused layer in fp32 on the map it leaves (channels_last, no
+    copy); detections stay within a fraction of a heat-map cell of the fp32 trunk's.  An option: the default is the reference's fp32."""
+    from epipolar_transformers_amd import synthetic as syn
+    from epipolar_transformers_amd.model import ring_sources
+
+    cfg, size, hs = _cfg()
+    m = _model(cfg)
+    frames, V = 2, 4
+    P = torch.from_numpy(syn.ring_cameras(V, size)).float().repeat(frames, 1, 1)
+    img = torch.randn(frames * V, 3, size, size, device="cuda")
+    src = ring_sources(frames, V, "cuda")
+    with torch.no_grad():
+        full = m.forward_views(img, P, src)
+        cfg.merge_from_list(["EPIPOLAR_AMD.TRUNK_DTYPE", dt])
+        low = m.forward_views(img, P, src)
+    assert low[0].dtype == torch.float32 and low[1][0].dtype == torch.float32
+    scale = full[0].abs().max().item()
+    assert 0 < (low[0] - full[0]).abs().max().item() <= (0.05 if dt == "bf16" else 0.01) * scale
+    assert torch.isfinite(low[2]).all()
+
+
 @pytest.mark.parametrize("share", [True, False])
 def test_multitest_picks_the_best_source_per_joint(share):
     """EPIPOLAR.MULTITEST (model.py:213-239): every other view as the source (features from `self.backbone`: the same
