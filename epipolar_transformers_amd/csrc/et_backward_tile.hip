@@ -108,7 +108,14 @@ int et_epipolar_backward_tiled_attn(const EtLayerDesc *desc, const float *xs, co
             // (two blocks per compute unit -- what is resident at once -- walk the list)
             const int cus = device_cus(dev);
             const unsigned lgrid = (unsigned)(total < 2LL * cus ? total : 2LL * cus);
-            if (tile_rows(desc) == kTileRowsSmall) {
+            if (tile_rows(desc) == kTileRowsSmall && ET_BWD_LIST_MERGED) {
+                // round 6: the deferred tiles of a 64 x 64 map (193 .. ~280 rows) by the MERGED kernel of 288 columns -- one
+                // derivation of the samples' slots for both arrays, no half passes (a tile beyond 288 rows is split there)
+                tp.rows_cap = kTileRowsMergedLarge;
+                lds = lds_of(kTileRowsMergedLarge, true);
+                ET_GRANT_LDS((epipolar_bwd_tile_list_kernel<1, kTileRowsMergedLarge>), lds, dev);
+                hipLaunchKernelGGL((epipolar_bwd_tile_list_kernel<1, kTileRowsMergedLarge>), dim3(lgrid), dim3(256), lds, st, tp);
+            } else if (tile_rows(desc) == kTileRowsSmall) {
                 ET_GRANT_LDS((epipolar_bwd_tile_list_kernel<1, kTileRowsSmall>), lds, dev);
                 hipLaunchKernelGGL((epipolar_bwd_tile_list_kernel<1, kTileRowsSmall>), dim3(lgrid), dim3(256), lds, st, tp);
             } else {

@@ -66,7 +66,8 @@ bool tile_ws_eligible(const EtLayerDesc *d)
 // Header words beyond [0] / [1] are scratch of the kernels of ONE call, cleared by tile_keys_kernel (`header`) at its start:
 //   forward:  [2 .. 9]  one tile counter per XCD (the blocks of an XCD draw their tiles from it)
 //   backward: [2] four-group tiles met so far, [3] eight-or-more-group tiles met early (kernels_backward_tile.inc: the merged
-//             kernel splits the first 128 / 32 of a call in place and defers the rest to its second launch)
+//             kernel splits the first 128 / 32 of a call in place and defers the rest to its second launch), [4] over-capacity
+//             tiles met so far (beyond the first 256 of a call they are deferred without a search)
 // The backward REUSES the forward's counter words: safe because every call starts with the ordering kernels on the same stream,
 // which zero them -- a change to either user has to keep that.  Which over-capacity tiles a backward call splits in
 // place and which it defers depends on the order its blocks reach those counters and on blockIdx relative to gridDim: the

@@ -551,7 +551,8 @@ def backward_deferred_tiles(device, header=False, workspace=None):
     """Tiles the most recent tiled backward on `device` (current stream, WHICHEVER host thread launched it: autograd runs the
     backward on a thread of its own) handed from the merged two-array kernel to the one-array kernel because their row set
     exceeds 192 (288) columns -- word 0 of the workspace that call used (or of `workspace`).  Synchronises; a diagnostic
-    (tests, profiling).  `header`: the tuple (deferred, -, four-group tiles met, eight-group tiles met early).  Which tiles
+    (tests, profiling).  `header`: the first eight header words, (deferred, error word, four-group tiles met,
+    eight-group tiles met early, over-capacity tiles met, ...).  Which tiles
     are deferred depends on the order the blocks of a launch reach them (et_tile_host.h): the count varies from run to run."""
     dev = torch.device(device)
     idx = dev.index if dev.index is not None else torch.cuda.current_device()
@@ -560,9 +561,9 @@ def backward_deferred_tiles(device, header=False, workspace=None):
         ref = _last_tile_backward_ws.get((idx, torch.cuda.current_stream(dev).cuda_stream))
         buf = ref() if ref is not None else None
     if buf is None:
-        return (0, 0, 0, 0) if header else 0
+        return (0,) * 8 if header else 0
     base = (-buf.data_ptr()) % 256
-    words = buf[base:base + 16].view(torch.int32).tolist()
+    words = buf[base:base + 32].view(torch.int32).tolist()       # (eight header words)
     return tuple(words) if header else words[0]
 
 

@@ -15,7 +15,11 @@ which = os.environ.get("PROF_KERNEL", "fwd")
 H, C, K = int(os.environ.get("PROF_HW", 64)), 256, int(os.environ.get("PROF_K", 64))
 dev = torch.device("cuda:0")
 NP, V = int(os.environ.get("PROF_PAIRS", 128)), int(os.environ.get("PROF_VIEWS", 4))      # (Config 5: PROF_PAIRS=64 PROF_VIEWS=8)
-P1, P2 = syn.make_pairs(NP // V, V, H * 4, seed=1000, jitter=(0.05, 8.0))
+RIG = os.environ.get("PROF_RIG", "ring")                                                   # (as scripts/bwd_ab.py's AB_RIG)
+if RIG == "ring":
+    P1, P2 = syn.make_pairs(NP // V, V, H * 4, seed=1000, jitter=(0.05, 8.0))
+else:
+    P1, P2 = syn.rig_pairs(RIG, NP // (4 if RIG == "h36m_room" else 2), 4 * H, seed=1000, jitter=None if RIG == "epipole_border" else (0.05, 8.0))
 g = torch.Generator(device=dev).manual_seed(0)
 ref = torch.randn(NP, H, H, C, device=dev, generator=g).relu_()
 src = torch.randn(NP, H, H, C, device=dev, generator=g).relu_()

@@ -233,3 +233,34 @@ def test_backward_policy_branches_at_the_headline_batch(env):
     gr_g, gs_g = ops.backward_nhwc(ops.LayerSpec(H=h, W=h, K=k), ref[:m], src[:m], cam[:m], gout[:m], form="gather")
     for a, b in ((gr_t, gr_g), (gs_t, gs_g)):
         assert (a - b).abs().max().item() <= 2e-5 * b.abs().max().item()
+
+
+def test_backward_many_over_capacity_tiles_are_deferred_at_once(env):
+    """Round 6: beyond the first 256 over-capacity tiles of a call the merged backward neither searches nor splits -- the tile goes to
+    the second launch, the merged kernel of 288 columns (64 x 64 maps).  The epipole-inside rig at a 32-pair batch has ~1 800 such
+    tiles (header word 4 counts them): nearly all deferred, gradients equal to the in-place policy's and to the gather form's, finite
+    everywhere (outputs are NaN-poisoned); tiles beyond 288 rows are split inside the second launch."""
+    _lib, camera, ops = env
+    from epipolar_transformers_amd import synthetic as syn
+    n, h, k = 32, 64, 64
+    P1, P2 = syn.rig_pairs("epipole_inside", n // 2, 4 * h, seed=1000, jitter=(0.05, 8.0))
+    cam = camera.pair_algebra(P1, P2).cuda()
+    g0 = torch.Generator(device="cuda").manual_seed(12)
+    ref = torch.randn(n, h, h, C, device="cuda", generator=g0).relu_()
+    src = torch.randn(n, h, h, C, device="cuda", generator=g0).relu_()
+    gout = torch.randn(n, h, h, C, device="cuda", generator=g0)
+    attn = ops.forward_nhwc(ops.LayerSpec(H=h, W=h, K=k), ref, src, cam)[1]
+    res = []
+    for variant in (0, _lib.ET_VARIANT_BWD_SPLIT_IN_PLACE):
+        gr, gs = ops.backward_nhwc(ops.LayerSpec(H=h, W=h, K=k, variant=variant), ref, src, cam, gout, attn=attn)
+        torch.cuda.synchronize()
+        res.append((gr, gs, ops.backward_deferred_tiles(ref.device, header=True)))
+    hdr = res[0][2]
+    assert hdr[4] > 1000 and hdr[0] >= hdr[4] - 256, hdr          # met > 1000, all but (at most) the first 256 deferred
+    assert res[1][2][0] == 0
+    for a, b in ((res[0][0], res[1][0]), (res[0][1], res[1][1])):
+        assert torch.isfinite(a).all() and torch.isfinite(b).all()
+        assert (a - b).abs().max().item() <= 2e-5 * b.abs().max().item()
+    gr_g, gs_g = ops.backward_nhwc(ops.LayerSpec(H=h, W=h, K=k), ref, src, cam, gout, form="gather")
+    for a, b in ((res[0][0], gr_g), (res[0][1], gs_g)):
+        assert (a - b).abs().max().item() <= 2e-5 * b.abs().max().item()

@@ -264,15 +264,20 @@ def test_persistent_kernels_are_stable_over_repeated_runs(H, K, N, variant, fuse
     ops.check_tile_errors()
 
 
-@pytest.mark.parametrize("H,K,N", [pytest.param(64, 64, 32, id="64x64-K64-N32"), pytest.param(96, 64, 12, id="96x96-K64-N12"),
-                                   pytest.param(128, 128, 4, id="128x128-K128-N4"), pytest.param(48, 33, 24, id="48x48-K33-N24")])
-def test_tiled_backward_is_stable_over_repeated_runs(H, K, N):
+@pytest.mark.parametrize("H,K,N,rig", [pytest.param(64, 64, 32, "ring", id="64x64-K64-N32"), pytest.param(96, 64, 12, "ring", id="96x96-K64-N12"),
+                                       pytest.param(128, 128, 4, "ring", id="128x128-K128-N4"), pytest.param(48, 33, 24, "ring", id="48x48-K33-N24"),
+                                       # (round 6: ~1 800 over-capacity tiles -> the second launch, epipolar_bwd_tile_list_kernel<1, 288>)
+                                       pytest.param(64, 64, 32, "epipole_inside", id="64x64-K64-N32-epipole-inside")])
+def test_tiled_backward_is_stable_over_repeated_runs(H, K, N, rig):
     """epipolar_bwd_tile_kernel (five split-fp16 GEMMs beside VALU phases; float atomics on d(feat_src): equal to rounding
     only), twenty NaN-poisoned runs against the bit-reproducible gather form."""
     from epipolar_transformers_amd import camera, ops, synthetic as syn
 
     dev = torch.device("cuda:0")
-    P1, P2 = syn.make_pairs((N + 3) // 4, 4, H * 4, seed=11 + N, jitter=(0.05, 8.0))
+    if rig == "ring":
+        P1, P2 = syn.make_pairs((N + 3) // 4, 4, H * 4, seed=11 + N, jitter=(0.05, 8.0))
+    else:
+        P1, P2 = syn.rig_pairs(rig, N // 2, 4 * H, seed=11 + N, jitter=(0.05, 8.0))
     P1, P2 = P1[:N], P2[:N]
     f1, f2 = syn.make_features(N, 256, H, H, seed=13)
     ref, src = f1.permute(0, 2, 3, 1).contiguous().to(dev), f2.permute(0, 2, 3, 1).contiguous().to(dev)
