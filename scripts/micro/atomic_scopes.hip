@@ -78,7 +78,8 @@ int main(int argc, char **argv)
     const unsigned rows = argc > 1 ? (unsigned)atoi(argv[1]) : 1u << 18;      // (1 KB each; default 256 MB)
     printf("array: %u rows of 1 KB = %.1f MB\n", rows, rows / 1024.0);
     float *dst; hipMalloc(&dst, (size_t)rows * 1024);
-    const int blocks = 2048, iters = 256;
+    const int blocks = argc > 2 ? atoi(argv[2]) : 2048, iters = argc > 3 ? atoi(argv[3]) : 256;      // (blocks of four waves)
+    printf("blocks %d x 4 waves, %d atomics per wave\n", blocks, iters);
     run<0>("buffer_atomic_fadd aux 0 (the backward's)", dst, rows, blocks, iters);
     run<5>("buffer_atomic_fadd aux sc1", dst, rows, blocks, iters);
     run<4>("__hip_atomic_fetch_add wavefront scope", dst, rows, blocks, iters);
