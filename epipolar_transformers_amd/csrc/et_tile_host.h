@@ -111,7 +111,8 @@ int launch_tile_order(const EtLayerDesc *desc, const float *xs, const float *ys,
     const int perm_stride = tiles_per_pair * kTilePix;
     int n2 = 64;
     while (n2 < HW) n2 <<= 1;
-    const size_t lds_sort = tile_order_lds_bytes(n2);
+    const size_t lds_sort = order_uses_radix(n2) ? ((tile_order_lds_bytes(n2) + 15) & ~(size_t)15) + order_radix_extra_bytes(n2)
+                                                 : tile_order_lds_bytes(n2);
     const int dev = current_device();
     ET_GRANT_LDS(tile_order_kernel, lds_sort, dev);
     unsigned long long *keys = reinterpret_cast<unsigned long long *>(w.segs);

@@ -8,8 +8,9 @@ from the workspace the forward leaves (layout: csrc/et_tile_host.h / include/epi
     decreases along `perm` by more than the key's resolution (a broken sorting network scrambles it);
   * pixels without a segment come last.
 
-Shapes: the bench's 64 x 64 (4096 keys: the sort's full three-stage rounds), 10 x 10 (100 pixels: a padded last tile, 128-key
-sort), 33 x 20 (non-square, 1024 keys), 96 x 96 (16384-key sort).
+Shapes: the bench's 64 x 64 (4096 keys), 10 x 10 (100 pixels: a padded last tile, 128-key bitonic sort), 33 x 20 (non-square, 1024
+keys), 96 x 96 (16384-key bitonic sort: the full three-stage rounds); 256 .. 4096 keys take the radix sort (round 6) -- one shape per
+width of its counter scan, with and without padding keys.
 """
 import math
 
@@ -43,8 +44,11 @@ def _regions(ws, n, h, w):
     return perm, segs, band, segs_pix
 
 
-@pytest.mark.parametrize("n,h,w,k", [(5, 64, 64, 64), (3, 10, 10, 16), (4, 33, 20, 20), (2, 96, 96, 64)],
-                         ids=["64x64", "10x10-padded-tile", "33x20", "96x96"])
+@pytest.mark.parametrize("n,h,w,k", [(5, 64, 64, 64), (3, 10, 10, 16), (4, 33, 20, 20), (2, 96, 96, 64),
+                                     # (round 6: 256 .. 4096 keys take the radix sort -- every counter-scan width of it)
+                                     (3, 16, 16, 16), (3, 15, 15, 16), (3, 20, 20, 16), (2, 40, 40, 32), (2, 48, 64, 48)],
+                         ids=["64x64", "10x10-padded-tile", "33x20", "96x96", "16x16-256-keys", "15x15-padded-256", "20x20-512-keys",
+                              "40x40-2048-keys", "48x64-padded-4096"])
 def test_tile_order_is_a_sorted_permutation_with_gathered_segments(n, h, w, k):
     assert torch.cuda.is_available(), "these tests need the MI355X"
     from epipolar_transformers_amd import camera, ops, synthetic as syn
