@@ -375,3 +375,10 @@ int validate(const EtLayerDesc *d)
 }
 
 }  // namespace
+
+// Internal to the library (hidden: not part of the C ABI), defined in et_residual_gemm.hip: x = feat + bias + out . Wf^T for the
+// pixel rows of a device-side LIST of tiles -- the fused forward's left-over tiles (et_forward_tile.hip).  Returns the status.
+__attribute__((visibility("hidden"))) int et_internal_residual_rows_list(const int *perm, const int *tile_list, const int *tile_count,
+                                                                         int tiles_per_pair, int HW, long long total_tiles,
+                                                                         const float *out, const float *feat, const unsigned *packed,
+                                                                         const float *bias, float *x, hipStream_t st);

@@ -6,57 +6,6 @@ namespace {
 #include "kernels_forward_tile.inc"     // tile_order_kernel, epipolar_fwd_tile_kernel / _list_kernel
 #include "kernels_forward_tile_ws.inc"  // epipolar_fwd_tile_ws_kernel (warp-specialised, persistent): the default
 
-// x rows of the tiles the fused persistent kernel handed to the overflow list (their `out` rows come from the one-block-per-
-// tile kernel): x = feat_ref + bias + out . Wf^T in plain fp32, thread n = output channel n.  Wf is rebuilt from the packed
-// fragments (hi + lo: the 22 significant bits the matrix-core path multiplies with).  A block takes EIGHT pixel rows of a tile
-// (round 5: with a whole tile per block and one block per compute unit the near-rectified rig's 640 overflow tiles took 0.16 ms,
-// a fifth of the layer; profiles/r05_rig_kernel_stats.txt).  Normally the list is empty and every block leaves at once.
-constexpr int kRowsListParts = 4, kRowsListPix = kTilePix / kRowsListParts;
-__global__ __launch_bounds__(256) void residual_rows_list_kernel(const int *__restrict__ perm, const int *__restrict__ tile_list,
-                                                                 const int *__restrict__ tile_count, int tiles_per_pair, int HW,
-                                                                 const float *__restrict__ out, const float *__restrict__ feat,
-                                                                 const unsigned *__restrict__ packed, const float *__restrict__ bias,
-                                                                 float *__restrict__ x)
-{
-    __shared__ float s_out[kRowsListPix][256];
-    __shared__ int s_px[kRowsListPix];
-    const int nch = threadIdx.x;                      // output channel
-    const int count = *tile_count * kRowsListParts;
-    if ((int)blockIdx.x >= count) return;
-    const float inv_w = reinterpret_cast<const float *>(packed)[kRgPackedWords];
-    for (int e = blockIdx.x; e < count; e += gridDim.x) {
-        const int tile = tile_list[e / kRowsListParts], part = e % kRowsListParts;
-        const size_t base = (size_t)(tile / tiles_per_pair) * HW * 256;
-        __syncthreads();
-        if (threadIdx.x < kRowsListPix) s_px[threadIdx.x] = perm[(size_t)tile * kTilePix + part * kRowsListPix + threadIdx.x];
-        __syncthreads();
-        for (int m = 0; m < kRowsListPix; ++m) s_out[m][nch] = s_px[m] >= 0 ? out[base + (size_t)s_px[m] * 256 + nch] : 0.f;
-        __syncthreads();
-        float acc[kRowsListPix];
-#pragma unroll
-        for (int m = 0; m < kRowsListPix; ++m) acc[m] = 0.f;
-        // fragment (ks, nb, term, lane): lane (n & 31, kg) holds Wf[n][16 ks + 8 kg .. + 7] (residual_gemm_pack_kernel)
-        const int nb = nch >> 5;
-        for (int ks = 0; ks < 16; ++ks)
-            for (int kg = 0; kg < 2; ++kg) {
-                const f16x8 *frag = reinterpret_cast<const f16x8 *>(packed) + ((size_t)(ks * 8 + nb) * 2) * 64 + (kg * 32 + (nch & 31));
-                const f16x8 hi = frag[0], lo = frag[64];
-#pragma unroll
-                for (int jj = 0; jj < 8; ++jj) {
-                    const float w = ((float)hi[jj] + (float)lo[jj]) * inv_w;
-                    const int k = ks * 16 + kg * 8 + jj;
-#pragma unroll
-                    for (int m = 0; m < kRowsListPix; ++m) acc[m] = fmaf(s_out[m][k], w, acc[m]);
-                }
-            }
-        const float b = bias[nch];
-        for (int m = 0; m < kRowsListPix; ++m)
-            if (s_px[m] >= 0) {
-                const size_t o = base + (size_t)s_px[m] * 256 + nch;
-                x[o] = (feat[o] + b) + acc[m];
-            }
-    }
-}
 }  // namespace
 #include "et_tile_host.h"
 
@@ -206,6 +155,9 @@ int et_epipolar_forward_tiled(const EtLayerDesc *desc, const float *xs, const fl
         } else if (rows == kTileRowsLarge) {
             ET_LIST(1, kTileRowsLarge);
         } else {
+            // (round 6, measured: the left-overs of a map up to 64 x 64 -- all beyond 256 rows -- through the 384-row instance, whole
+            //  instead of in pixel groups, take as long: 136 against 131 us for the near-rectified rig's 640 tiles.  A left-over tile
+            //  is ~65 us of latency in a block either way and the list is two trips of the resident blocks.)
             ET_LIST(1, kTileRowsSmall);
         }
 #undef ET_LIST
@@ -331,11 +283,10 @@ int et_epipolar_forward_fused(const EtLayerDesc *desc, const float *xs, const fl
         hipLaunchKernelGGL((epipolar_fwd_tile_list_kernel<1, kTileRowsSmall>), dim3(lgrid), dim3(256), lds, st, tp);
     }
     if (int e = check_launch("et_epipolar_forward_fused(list)")) return e;
-    const long long row_items = (long long)total * kRowsListParts;
-    hipLaunchKernelGGL(residual_rows_list_kernel, dim3((unsigned)(row_items < 8LL * cus ? row_items : 8LL * cus)), dim3(256), 0, st, w.perm,
-                       w.ovf_list, w.ovf_count, tp.tiles_per_pair, HW, out_scratch, feat_ref,
-                       reinterpret_cast<const unsigned *>(packed_w), bias, x);
-    return check_launch("et_epipolar_forward_fused(list rows)");
+    // their x rows: the residual GEMM kernel over the list, two tiles per block and trip (round 6: the plain-fp32 kernel this replaces
+    // took 76 us for the near-rectified rig's 640 left-over tiles -- 256 KB of weight fragments per eight pixel rows; now 24 us)
+    return et_internal_residual_rows_list(w.perm, w.ovf_list, w.ovf_count, tp.tiles_per_pair, HW, total, out_scratch, feat_ref,
+                                          reinterpret_cast<const unsigned *>(packed_w), bias, x, st);
 }
 
 }  // extern "C"

@@ -6,6 +6,20 @@ namespace {
 #include "kernels_residual_gemm.inc"
 }  // namespace
 
+int et_internal_residual_rows_list(const int *perm, const int *tile_list, const int *tile_count, int tiles_per_pair, int HW,
+                                   long long total_tiles, const float *out, const float *feat, const unsigned *packed,
+                                   const float *bias, float *x, hipStream_t st)
+{
+    const int dev = current_device();
+    auto kern = residual_gemm_kernel<true, false, false, true>;
+    ET_GRANT_LDS(kern, kRgLdsBytes, dev);
+    // two blocks per compute unit -- what is resident at once -- walk the list, two tiles per trip
+    const long long want = (total_tiles + 1) / 2, cap = 2LL * device_cus(dev);
+    hipLaunchKernelGGL(kern, dim3((unsigned)(want < cap ? want : cap)), dim3(256), kRgLdsBytes, st, out, feat, packed, bias, x, 0LL,
+                       (float *)nullptr, (const float *)nullptr, 1, perm, tile_list, tile_count, tiles_per_pair, HW);
+    return check_launch("et_epipolar_forward_fused(list rows)");
+}
+
 extern "C" {
 
 size_t et_residual_gemm_packed_bytes(void) { return (size_t)kRgPackedWords * 4 + 256; }
@@ -68,7 +82,8 @@ int et_z_batch_stats(int64_t num_pixels, int32_t C, const float *out, const void
     ET_GRANT_LDS(kern, kRgLdsBytes, dev);
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), kRgLdsBytes, st, out, (const float *)nullptr,
                        reinterpret_cast<const unsigned *>(packed_wz), z_bias, y, (long long)num_pixels,
-                       reinterpret_cast<float *>(workspace), static_cast<const float *>(nullptr), 1);
+                       reinterpret_cast<float *>(workspace), static_cast<const float *>(nullptr), 1, (const int *)nullptr,
+                       (const int *)nullptr, (const int *)nullptr, 0, 0);
     if (int e = check_launch("et_z_batch_stats(gemm)")) return e;
     hipLaunchKernelGGL(z_stats_finish_kernel, dim3(256), dim3(256), 0, st, reinterpret_cast<const float *>(workspace), blocks,
                        (long long)num_pixels, z_bias, mean, var);
@@ -112,7 +127,8 @@ int et_z_backward(int64_t num_pixels, int32_t C, const float *g, const float *y,
     auto kern = residual_gemm_kernel<true, false, true>;
     ET_GRANT_LDS(kern, kRgLdsBytes, dev);
     hipLaunchKernelGGL(kern, dim3((unsigned)gblocks), dim3(256), kRgLdsBytes, st, y, g, reinterpret_cast<const unsigned *>(packed_wzt),
-                       static_cast<const float *>(nullptr), grad_out, (long long)num_pixels, grad_y, coef, (int)(zresidual != 0));
+                       static_cast<const float *>(nullptr), grad_out, (long long)num_pixels, grad_y, coef, (int)(zresidual != 0),
+                       (const int *)nullptr, (const int *)nullptr, (const int *)nullptr, 0, 0);
     return check_launch("et_z_backward(gemm)");
 }
 

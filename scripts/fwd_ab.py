@@ -10,7 +10,12 @@ label = sys.argv[1] if len(sys.argv) > 1 else os.path.basename(os.environ.get("E
 dev = torch.device("cuda:0")
 H, C, K = int(os.environ.get("AB_HW", "64")), 256, int(os.environ.get("AB_K", "64"))      # (Config 5: AB_HW=128 AB_K=128 AB_PAIRS=64 AB_VIEWS=8)
 NP, V = int(os.environ.get("AB_PAIRS", "128")), int(os.environ.get("AB_VIEWS", "4"))
-P1, P2 = syn.make_pairs(NP // V, V, H * 4, seed=1000, jitter=(0.05, 8.0))
+RIG = os.environ.get("AB_RIG", "ring")           # (ring | h36m_room | epipole_inside | epipole_border | near_rectified_y: synthetic.rig_pairs)
+if RIG == "ring":
+    P1, P2 = syn.make_pairs(NP // V, V, H * 4, seed=1000, jitter=(0.05, 8.0))
+else:
+    P1, P2 = syn.rig_pairs(RIG, NP // (4 if RIG == "h36m_room" else 2), 4 * H, seed=1000, jitter=None if RIG == "epipole_border" else (0.05, 8.0))
+    label += " [%s]" % RIG
 g = torch.Generator(device=dev).manual_seed(0)
 ref = torch.randn(NP, H, H, C, device=dev, generator=g).relu_()
 src = torch.randn(NP, H, H, C, device=dev, generator=g).relu_()
