@@ -577,7 +577,7 @@ def train_step(dev, H, W, C, K, feat_ref, feat_src, P_ref, P_src, reps=8):
     that keeps `out` and the attention for autograd (ops.EpipolarAttend), then z (1x1 convolution) + batch-norm with BATCH
     statistics + both residual adds as two passes of the hand-written GEMM kernel (et_z_batch_stats, et_residual_gemm with the
     statistics folded in), then the backward of all of it with a given d(loss)/dx: et_z_backward (the batch norm's sums +
-    the GEMM kernel forming dy on the fly) and et_z_wgrad (exact-fp32 MFMAs contracted over the rows) for the epilogue, the MFMA
+    the GEMM kernel forming dy on the fly) and et_z_wgrad (three-term bf16 MFMAs contracted over the rows) for the epilogue, the MFMA
     tile backward (re-using the saved attention) for the layer -- with gradients for both feature maps and the four parameters.  HIP events around whole steps; the roofline figure is the
     layer's forward + backward algorithmic bytes over the step time."""
     from epipolar_transformers_amd import default_cfg
@@ -630,7 +630,7 @@ def train_step(dev, H, W, C, K, feat_ref, feat_src, P_ref, P_src, reps=8):
             "algorithmic_bytes": fb + bb, "frac_of_hbm_peak": (fb + bb) / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
             "kernels": "forward: tile_keys + tile_order + epipolar_fwd_tile_ws_kernel (out, attention kept for autograd), then "
                        "residual_gemm_kernel<stats> + z_stats_finish + 2 weight packs + residual_gemm_kernel (batch statistics folded "
-                       "in); backward: z_bwd_sums + z_bwd_finish + residual_gemm_kernel<dy> + z_wgrad_kernel + z_wgrad_finish, then "
+                       "in); backward: z_bwd_sums + z_bwd_finish + residual_gemm_kernel<dy> + z_wgrad_bf16x3_kernel + z_wgrad_finish, then "
                        "tile_keys + tile_order + epipolar_bwd_tile_kernel (saved attention)",
             "note": "train mode, gradients w.r.t. feat_ref, feat_src, z.weight, z.bias, bn.weight, bn.bias; d(loss)/dx given"}
 

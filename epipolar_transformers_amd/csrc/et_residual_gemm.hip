@@ -1,6 +1,10 @@
 // libepipolar_amd.so: the eval-mode residual fusion as one GEMM (C = 256) -- et_residual_gemm_pack, et_residual_gemm.
 #include "et_common.h"
 
+#ifndef ET_WGRAD_FP32
+#define ET_WGRAD_FP32 0
+#endif
+
 namespace {
 #include "et_wave_reduce.h"
 #include "kernels_residual_gemm.inc"
@@ -164,8 +168,14 @@ int et_z_wgrad(int64_t num_pixels, int32_t C, const float *grad_y, const float *
     // (the kernel forms byte offsets into a block's share as 32-bit ints: (k * 16 + row) * 1024 + chunk)
     if ((per + kWgRows) * 1024 >= (1LL << 31)) return fail("et_z_wgrad: a block's share of the rows must stay below 2 GiB");
     float *pw = reinterpret_cast<float *>(workspace), *pb = pw + (size_t)blocks * 65536;
+#if ET_WGRAD_FP32      // (development: the exact-fp32 MFMA form of rounds 5-6)
     ET_GRANT_LDS(z_wgrad_kernel, kWgLdsBytes, dev);
     hipLaunchKernelGGL(z_wgrad_kernel, dim3((unsigned)blocks), dim3(512), kWgLdsBytes, st, grad_y, out, (long long)num_pixels, per, pw, pb);
+#else
+    ET_GRANT_LDS(z_wgrad_bf16x3_kernel, kWgbLdsBytes, dev);
+    hipLaunchKernelGGL(z_wgrad_bf16x3_kernel, dim3((unsigned)blocks), dim3(512), kWgbLdsBytes, st, grad_y, out, (long long)num_pixels, per,
+                       pw, pb);
+#endif
     if (int e = check_launch("et_z_wgrad")) return e;
     hipLaunchKernelGGL(z_wgrad_finish_kernel, dim3(257), dim3(256), 0, st, pw, pb, blocks, grad_w, grad_b);
     return check_launch("et_z_wgrad(finish)");

@@ -682,7 +682,7 @@ def z_backward(g: torch.Tensor, y: torch.Tensor, mean: torch.Tensor, invstd: tor
 
 def z_wgrad(grad_y: torch.Tensor, out: torch.Tensor):
     """d Wz (256, 256) = grad_y^T @ out and d bz (256) = grad_y.sum(rows) over (..., 256) contiguous tensors (et_z_wgrad:
-    exact fp32 MFMAs, no atomics)."""
+    three-term bf16 MFMAs with fp32 accumulation, no atomics, bit-reproducible)."""
     _require_gpu(grad_y, "grad_y")
     _require_gpu(out, "out")
     c = out.shape[-1]

@@ -298,9 +298,10 @@ int et_z_backward(int64_t num_pixels, int32_t C, const float *g, const float *y,
                   float *grad_beta, void *workspace, size_t workspace_bytes, void *stream);
 
 /* The weight gradient that closes et_z_backward (ABI 12): grad_w (256 out x 256 in) = grad_y^T . out and grad_b (256) =
- * sum_rows grad_y over the num_pixels rows -- a GEMM contracted over the rows, in exact fp32 MFMAs (v_mfma_f32_32x32x2_f32),
+ * sum_rows grad_y over the num_pixels rows -- a GEMM contracted over the rows on the matrix cores (each fp32 value as three bf16
+ * terms, six cross terms per product, fp32 accumulation: no scale, no range limit; rounds 5-6: exact fp32 MFMAs),
  * one block per compute unit, per-block partial results in `workspace` (et_z_wgrad_workspace_bytes bytes, no initialisation
- * needed) summed in block order: no float atomics, bit-reproducible. */
+ * needed) summed in a fixed order: no float atomics, bit-reproducible. */
 size_t et_z_wgrad_workspace_bytes(int64_t num_pixels);
 int et_z_wgrad(int64_t num_pixels, int32_t C, const float *grad_y, const float *out, float *grad_w, float *grad_b, void *workspace,
                size_t workspace_bytes, void *stream);

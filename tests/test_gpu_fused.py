@@ -270,13 +270,14 @@ def test_z_backward_vs_float64_autograd(env, rows, zres):
 
 @pytest.mark.parametrize("rows", [5, 16 * 7, 1587, 70000, 128 * 64 * 64], ids=["5", "112", "ragged-1587", "70000", "config2"])
 def test_z_wgrad_vs_float64(env, rows):
-    """et_z_wgrad (d Wz = dy^T out, d bz = sum dy: exact fp32 MFMAs contracted over the rows, per-block partials summed in block
-    order) against float64, and bit-reproducible."""
+    """et_z_wgrad (d Wz = dy^T out, d bz = sum dy: contracted over the rows on the matrix cores -- three bf16 terms per value, six
+    cross terms per product, fp32 accumulation --, per-block partials summed in a fixed order) against float64 within the bound of an
+    fp32 accumulation, and bit-reproducible."""
     _lib, camera, ops = env
     g0 = torch.Generator(device="cuda").manual_seed(rows)
     dy = torch.randn(rows, C, device="cuda", generator=g0)
     out = torch.randn(rows, C, device="cuda", generator=g0).relu_()
-    dy[:, 7] *= 1e4            # (no fp16 anywhere: magnitudes do not matter)
+    dy[:, 7] *= 1e4            # (no fp16 anywhere -- bf16 keeps fp32's exponent: magnitudes do not matter)
     out[:, 9] *= 1e-6
     gw, gb = ops.z_wgrad(dy, out)
     gw2, gb2 = ops.z_wgrad(dy, out)
