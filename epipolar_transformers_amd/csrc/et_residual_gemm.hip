@@ -32,7 +32,7 @@ int et_residual_gemm_pack(const float *wf, void *packed, void *stream)
 {
     if (!wf || !packed) return fail("et_residual_gemm_pack: NULL pointer");
     if (reinterpret_cast<uintptr_t>(packed) & 15) return fail("et_residual_gemm_pack: packed buffer must be 16-byte aligned");
-    hipLaunchKernelGGL(residual_gemm_pack_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, wf,
+    hipLaunchKernelGGL(residual_gemm_pack_kernel, dim3(kRgPackBlocks), dim3(1024), 0, (hipStream_t)stream, wf,
                        reinterpret_cast<unsigned *>(packed));
     return check_launch("et_residual_gemm_pack");
 }
