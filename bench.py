@@ -342,14 +342,20 @@ def main():
     for _ in range(2 * RING + 2):
         layer_step()
     barrier()
+    import gc
+    gc.collect()
+    gc.disable()                          # (no collector pause inside the timed steps; re-enabled right behind them)
     for _ in range(args.warmup):
         layer_step()
     barrier()
     t0 = time.perf_counter()
+    host_marks = []                       # (host-side pace of the loop: a diagnostic of a slow or stalled host, extra.step_host_ms)
     for _ in range(args.steps):
         layer_step()
+        host_marks.append(time.perf_counter())
     barrier()
     elapsed = time.perf_counter() - t0
+    gc.enable()
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -533,6 +539,10 @@ def main():
     }
     if rg is not None:
         result["extra"]["residual_gemm"] = rg
+    gaps = sorted((b - a) * 1e3 for a, b in zip([t0] + host_marks[:-1], host_marks))
+    result["extra"]["step_host_ms"] = {"min": gaps[0], "p50": gaps[len(gaps) // 2], "max": gaps[-1],
+                                       "note": "wall time between consecutive returns of the step's launches on the host (it runs "
+                                               "up to four steps ahead of the device): a maximum far above ms_per_step is a host stall"}
 
     ops.check_tile_errors()                  # the sticky device-side error word of the tile forward (synchronises)
     if rank == 0 and exchange is None and C == 256:
@@ -713,7 +723,11 @@ def other_config(dev, hw, samples, views, frames, name, C=256):
 
     f_st = event_stats(lambda: ops.forward_nhwc(spec, ref, src, cam), reps=8, warm=3)
     f_ms = f_st["mean"]
-    attn = ops.forward_nhwc(spec, ref, src, cam)[1]
+    ws_o = ops.tile_workspace(spec, n, C, dev)                 # (a workspace of its own: its header word 0 = the left-over tiles)
+    attn = ops.forward_nhwc(spec, ref, src, cam, workspace=ws_o)[1]
+    torch.cuda.synchronize()
+    f_overflow = int(ws_o[(-ws_o.data_ptr()) % 256:][:4].view(torch.int32).item()) if ws_o.numel() else None
+    del ws_o
     b_st = event_stats(lambda: ops.backward_nhwc(spec, ref, src, cam, gout, attn=attn), reps=8, warm=4)
     b_ms = b_st["mean"]
     b_deferred = ops.backward_deferred_tiles(dev)
@@ -743,7 +757,7 @@ def other_config(dev, hw, samples, views, frames, name, C=256):
             "layer_kernels": (ws_name % "true") if one_kernel else "the forward kernel + residual_gemm_kernel",
             "backward_ms": b_ms, "backward_frac_of_hbm_peak": bb / (b_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
             "forward_stats_ms": f_st, "backward_stats_ms": b_st, "backward_deferred_tiles": b_deferred,
-            "tiles": n * ((hw * hw + 31) // 32),
+            "forward_leftover_tiles": f_overflow, "tiles": n * ((hw * hw + 31) // 32),
             "algorithmic_bytes_forward": fb, "algorithmic_bytes_backward": bb}
 
 
